@@ -1,0 +1,186 @@
+/*
+ * kiss_hip.h -- C ABI of libkiss_hip.so: the MI355X (gfx950) implementation of the
+ * jhhung/kISS hot path (k-ordered induced suffix sorting of DNA + FM-index queries).
+ *
+ * The reference has no FFI: its seam is the compile-time C++ facade
+ *   biovoltron::KISS1Sorter<size_type>::get_suffix_array_dna(S, k, num_threads)
+ *     (include/biovoltron/algo/sort/kiss1_sorter.hpp:20-26) ->
+ *   kiss::kiss1_suffix_array_dna<uint8_t,uint32_t>(S, SA, k, num_threads)
+ *     (include/biovoltron/algo/sort/kiss1_core.hpp:229-268)
+ * and, for queries,
+ *   FMIndex<4,uint32_t,KISS1Sorter<uint32_t>>::get_range / get_offsets
+ *     (include/biovoltron/algo/align/exact_match/fm_index.hpp:453-501,553-584).
+ * The entry points below are what a cgo/ctypes/C++ binding for that path binds
+ * (see INTEGRATION.md).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions: every function returns 0 (KISS_HIP_OK) or a negative kiss_hip_status.
+ * No exceptions cross the ABI.  Host buffers are owned by the caller.  Device
+ * workspace is owned by a kiss_hip_ctx.  A ctx is bound to one HIP device and must
+ * not be used from two threads at once; distinct ctxs are independent.
+ */
+#ifndef KISS_HIP_H
+#define KISS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KISS_HIP_VERSION 100 /* 0.1.0 */
+
+typedef enum kiss_hip_status {
+    KISS_HIP_OK = 0,
+    KISS_HIP_E_INVALID = -1,     /* bad argument (null pointer, n too large, unknown algo) */
+    KISS_HIP_E_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    KISS_HIP_E_HIP = -3,         /* a HIP runtime call failed (see kiss_hip_last_hip_error) */
+    KISS_HIP_E_NOMEM = -4,       /* device or host allocation failed */
+    KISS_HIP_E_UNSUPPORTED = -5, /* valid request outside the implemented range (documented) */
+    KISS_HIP_E_INTERNAL = -6     /* an internal invariant failed (bug) */
+} kiss_hip_status;
+
+/* Sorting algorithm selector; mirrors kISS::SortingAlgorithm
+ * (include/utils/constant.hpp, command/suffix_sort.hpp:38-48). */
+#define KISS_HIP_ALGO_PARALLEL_SORTING 0 /* KISS1: k-ordered LMS sort (kiss1_core.hpp)   */
+#define KISS_HIP_ALGO_PREFIX_DOUBLING 1  /* KISS2: only k >= n (exact SA) is a function of the input */
+
+/* the reference's size_type is uint32_t and EMPTY = 0xFFFFFFFF, so n + 19 < 2^32
+ * (algo/sort/structs.hpp:94, constant.hpp:19-20) */
+#define KISS_HIP_MAX_N 4294967276ull
+
+typedef struct kiss_hip_ctx kiss_hip_ctx;
+
+/* Per-call statistics (filled by kiss_hip_get_stats after a sort on that ctx). */
+typedef struct kiss_hip_stats {
+    uint64_t n;              /* text length */
+    uint64_t m;              /* number of LMS suffixes (without the sentinel) */
+    uint32_t k;              /* requested order */
+    uint32_t depth;          /* effective comparison depth D (0 = unbounded) */
+    uint32_t lms_rounds;     /* 32-base refinement rounds executed */
+    uint32_t induce_passes;  /* stable-partition passes executed by the two sweeps */
+    uint64_t near_end;       /* LMS suffixes ranked by the near-end rule */
+    uint64_t sort_item_rounds; /* sum over rounds of active LMS items */
+    float ms_total;          /* device time of the whole call (HIP events) */
+    float ms_pack;           /* 2-bit packing */
+    float ms_classify;       /* get_lms: classification + LMS extraction */
+    float ms_lms_sort;       /* k-ordered LMS sort (all rounds) */
+    float ms_place;          /* near-end ranking + merge + context gather */
+    float ms_induce;         /* L and S sweeps */
+    /* live per-kernel-class timing, only when profiling is enabled on the ctx */
+    float ms_kernel[16];
+    uint64_t launches_kernel[16];
+    uint64_t items_kernel[16]; /* units processed (items for radix/induce, bases for classify) */
+} kiss_hip_stats;
+
+/* kernel classes for ms_kernel[] / launches_kernel[] */
+enum {
+    KISS_HIP_K_PACK = 0,
+    KISS_HIP_K_CLASSIFY = 1,
+    KISS_HIP_K_RADIX_HIST = 2,
+    KISS_HIP_K_RADIX_SCATTER = 3,
+    KISS_HIP_K_SCAN = 4,
+    KISS_HIP_K_KEYGATHER = 5,
+    KISS_HIP_K_FLAG_COMPACT = 6,
+    KISS_HIP_K_PLACE = 7,
+    KISS_HIP_K_INDUCE_COUNT = 8,
+    KISS_HIP_K_INDUCE_SCATTER = 9,
+    KISS_HIP_K_INDUCE_SMALL = 10,
+    KISS_HIP_K_FM_QUERY = 11,
+    KISS_HIP_K_FM_BUILD = 12,
+    KISS_HIP_K_NCLASSES = 13
+};
+
+int kiss_hip_version(void);
+const char *kiss_hip_strerror(int status);
+/* number of visible HIP devices (does not initialise a context) */
+int kiss_hip_device_count(int *count);
+
+/* ---- context: device workspace sized for texts up to max_n bases ------------- */
+int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n);
+int kiss_hip_ctx_destroy(kiss_hip_ctx *ctx);
+/* enable/disable per-kernel HIP-event timing (adds event overhead; off by default) */
+int kiss_hip_ctx_set_profiling(kiss_hip_ctx *ctx, int enabled);
+/* last hipError_t seen by this ctx (0 = hipSuccess) and its string */
+int kiss_hip_last_hip_error(const kiss_hip_ctx *ctx, const char **msg);
+int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out);
+/* bytes of device workspace the ctx holds */
+int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes);
+
+/* ---- suffix sorting --------------------------------------------------------- */
+/*
+ * Replaces KISS1Sorter<uint32_t>::get_suffix_array_dna(S, k, num_threads)
+ * (kiss1_sorter.hpp:20-26) / KISS2Sorter (kiss2_sorter.hpp:20-26).
+ *   S  : n bytes, each in 0..3 (A C G T), host memory.  Only the low 2 bits are used.
+ *   k  : order; 0xFFFFFFFF (the CLI's -k -1) or any k >= n means the exact suffix array.
+ *   SA : caller-allocated, n+1 entries; SA[0] = n (sentinel), SA[1..n] a permutation.
+ * One-shot: creates a ctx on `device`, uploads, sorts, downloads, frees.
+ * n == 0 yields SA = {0} (kiss1_core.hpp:237-238).
+ */
+int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device);
+
+/* Same, on an existing ctx with host buffers (upload + sort + download). */
+int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, int algo,
+                                     uint32_t *SA);
+
+/* Device-resident form: d_S (n bytes) and d_SA (n+1 u32) are DEVICE pointers on the
+ * ctx's device.  stream is a hipStream_t (NULL = the ctx's own stream).  The call
+ * returns after the work on `stream` has completed. */
+int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo,
+                                         uint32_t *d_SA, void *stream);
+
+/* Stage outputs of the LAST sort on this ctx, for stage-level parity tests
+ * (get_lms: kiss_common.hpp:543-579; lms_suffix_direct_sort_dna: kiss1_core.hpp:24-145).
+ *   lms_ascending : m entries (text order), may be NULL
+ *   lms_sorted    : m entries (k-order, sentinel excluded), may be NULL
+ *   counts        : 12 entries {count[c], s_type_count[c], lms_count[c]} c = A,C,G,T, may be NULL
+ * Host pointers. */
+int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, uint32_t *lms_sorted,
+                                   uint64_t *counts);
+
+/* ---- FM-index (biovoltron FMIndex<4,uint32_t,...>{LOOKUP_LEN=0}) --------------- */
+/* Raw views of the arrays of the .fmi layout (fm_index.hpp:591-615).
+ * For the *_dev call every pointer is a device pointer. */
+typedef struct kiss_hip_fmi_view {
+    uint64_t n_sa;        /* N = n + 1 */
+    uint32_t cnt[4];      /* fm_index.hpp:296-307 */
+    uint32_t pri;         /* SA index i with SA[i] == 0 (:324-325) */
+    uint32_t sa_intv;     /* SA sampling interval (4) */
+    const uint8_t *bwt;   /* ceil(N/4) bytes, dibit i at bits 2(i%4) of byte i/4 (:317-328) */
+    const uint32_t *occ1; /* (N/256+1) x 4 (:280,283-301) */
+    const uint8_t *occ2;  /* (N/16+1) x 4 (:281,286-287) */
+    const uint32_t *sa;   /* sampled SA values, ceil(N/4) (:358-369) */
+    const uint64_t *b;    /* bit i = (SA[i] % sa_intv == 0), ceil(N/64) words (:338-350) */
+    const uint32_t *b_occ;/* N/64+1 (:339,352-356) */
+} kiss_hip_fmi_view;
+
+/*
+ * Batched backward search + locate; replaces the per-pattern loop of
+ * fmindex_query_main (include/command/fmindex_query.hpp:79-95):
+ *   get_range(pattern) (fm_index.hpp:553-584) then get_offsets(beg,end) (:453-501).
+ *   patterns : Q x L bytes in 0..3, row-major (device)
+ *   beg,end  : Q entries each (device), the SA range per pattern
+ *   hit_count_total, checksum : host pointers; sum of (end-beg) and sum of all hit positions
+ *   offsets / offsets_index : optional device buffers; offsets_index has Q+1 entries
+ *       (exclusive prefix of hit counts), offsets receives the hit positions of pattern q
+ *       at [offsets_index[q], offsets_index[q+1]) in get_offsets order; pass NULL to skip.
+ *   offsets_capacity : entries available in `offsets`
+ */
+int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi, const uint8_t *patterns, uint32_t L,
+                                 uint64_t Q, uint32_t *beg, uint32_t *end, uint64_t *hit_count_total,
+                                 uint64_t *checksum, uint32_t *offsets, uint64_t *offsets_index,
+                                 uint64_t offsets_capacity, void *stream);
+
+/*
+ * FM-index construction from a text and its suffix array, both device resident
+ * (FMIndex::build(ref, ori_sa), fm_index.hpp:390-451).  Output arrays are device
+ * buffers sized as in kiss_hip_fmi_view; cnt/pri are written to the host struct.
+ */
+int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, const uint32_t *d_SA, uint32_t sa_intv,
+                           uint8_t *d_bwt, uint32_t *d_occ1, uint8_t *d_occ2, uint32_t *d_sa_sampled, uint64_t *d_b,
+                           uint32_t *d_b_occ, uint32_t cnt_out[4], uint32_t *pri_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KISS_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libkiss_hip.so (the C ABI declared in include/kiss_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to
+load, importing the entry points raises.  (The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkiss_hip.so")
+
+KISS_HIP_OK = 0
+ALGO_PARALLEL_SORTING = 0
+ALGO_PREFIX_DOUBLING = 1
+MAX_N = 4294967276
+
+KERNEL_CLASSES = [
+    "pack", "classify", "radix_hist", "radix_scatter", "scan", "keygather", "flag_compact",
+    "place", "induce_count", "induce_scatter", "induce_small", "fm_query", "fm_build",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint64), ("m", ctypes.c_uint64), ("k", ctypes.c_uint32), ("depth", ctypes.c_uint32),
+        ("lms_rounds", ctypes.c_uint32), ("induce_passes", ctypes.c_uint32), ("near_end", ctypes.c_uint64),
+        ("sort_item_rounds", ctypes.c_uint64),
+        ("ms_total", ctypes.c_float), ("ms_pack", ctypes.c_float), ("ms_classify", ctypes.c_float),
+        ("ms_lms_sort", ctypes.c_float), ("ms_place", ctypes.c_float), ("ms_induce", ctypes.c_float),
+        ("ms_kernel", ctypes.c_float * 16), ("launches_kernel", ctypes.c_uint64 * 16),
+        ("items_kernel", ctypes.c_uint64 * 16),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if not k.endswith("_kernel")}
+        d["kernels"] = {
+            name: {"ms": self.ms_kernel[i], "launches": self.launches_kernel[i], "items": self.items_kernel[i]}
+            for i, name in enumerate(KERNEL_CLASSES)
+        }
+        return d
+
+
+class FmiView(ctypes.Structure):
+    _fields_ = [
+        ("n_sa", ctypes.c_uint64), ("cnt", ctypes.c_uint32 * 4), ("pri", ctypes.c_uint32),
+        ("sa_intv", ctypes.c_uint32), ("bwt", ctypes.c_void_p), ("occ1", ctypes.c_void_p),
+        ("occ2", ctypes.c_void_p), ("sa", ctypes.c_void_p), ("b", ctypes.c_void_p), ("b_occ", ctypes.c_void_p),
+    ]
+
+
+class KissHipError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, strerror(status), status)
+        if detail:
+            msg += " [" + detail + "]"
+        super().__init__(msg)
+
+
+_lib = None
+
+
+def load():
+    """Load libkiss_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libkiss_hip.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C kiss_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u8p = ctypes.c_void_p, ctypes.c_void_p
+    lib.kiss_hip_version.restype = ctypes.c_int
+    lib.kiss_hip_strerror.restype = ctypes.c_char_p
+    lib.kiss_hip_strerror.argtypes = [ctypes.c_int]
+    lib.kiss_hip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    lib.kiss_hip_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_uint64]
+    lib.kiss_hip_ctx_destroy.argtypes = [vp]
+    lib.kiss_hip_ctx_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.kiss_hip_last_hip_error.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
+    lib.kiss_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.kiss_hip_ctx_workspace_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.kiss_hip_suffix_sort_dna_u32.argtypes = [u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, ctypes.c_int]
+    lib.kiss_hip_ctx_suffix_sort_dna_u32.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp]
+    lib.kiss_hip_ctx_suffix_sort_dna_u32_dev.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, vp]
+    lib.kiss_hip_ctx_get_stage_outputs.argtypes = [vp, vp, vp, vp]
+    lib.kiss_hip_fmi_query_batch_dev.argtypes = [
+        vp, ctypes.POINTER(FmiView), vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
+        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp, ctypes.c_uint64, vp]
+    lib.kiss_hip_fmi_build_dev.argtypes = [
+        vp, vp, ctypes.c_uint64, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp,
+        ctypes.POINTER(ctypes.c_uint32 * 4), ctypes.POINTER(ctypes.c_uint32), vp]
+    for name in ("kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy", "kiss_hip_ctx_set_profiling",
+                 "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
+                 "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32",
+                 "kiss_hip_ctx_suffix_sort_dna_u32_dev", "kiss_hip_ctx_get_stage_outputs",
+                 "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev"):
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def strerror(status):
+    return load().kiss_hip_strerror(int(status)).decode()
+
+
+# every symbol include/kiss_hip.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = [
+    "kiss_hip_version", "kiss_hip_strerror", "kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy",
+    "kiss_hip_ctx_set_profiling", "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
+    "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32_dev",
+    "kiss_hip_ctx_get_stage_outputs", "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
+]

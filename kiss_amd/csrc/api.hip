@@ -1,0 +1,351 @@
+// api.hip -- the C ABI of libkiss_hip.so (declared in include/kiss_hip.h) and the suffix-sort driver.
+//
+// Driver = the GPU counterpart of kiss::kiss1_suffix_array_dna
+// (reference include/biovoltron/algo/sort/kiss1_core.hpp:229-268):
+//   pack -> get_lms -> k-ordered LMS sort -> (near-end rule, merge, context gather) -> L/S induction.
+#include "kiss_internal.hpp"
+#include <cstring>
+#include <new>
+
+// ---- profiling timers ----------------------------------------------------------------
+KTimer::KTimer(kiss_hip_ctx *c, int cls, uint64_t items) : ctx(c), idx(-1)
+{
+    if (!ctx->profiling) return;
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        kiss_hip_ctx::Ev e;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+        e.cls = 0;
+        ctx->ev_pool.push_back(e);
+    }
+    idx = (int)ctx->ev_used++;
+    ctx->ev_pool[idx].cls = cls;
+    ctx->stats.launches_kernel[cls]++;
+    ctx->stats.items_kernel[cls] += items;
+    (void)hipEventRecord(ctx->ev_pool[idx].a, ctx->stream);
+}
+KTimer::~KTimer()
+{
+    if (idx >= 0) (void)hipEventRecord(ctx->ev_pool[idx].b, ctx->stream);
+}
+void ktimer_collect(kiss_hip_ctx *ctx)
+{
+    for (size_t i = 0; i < ctx->ev_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[i].a, ctx->ev_pool[i].b) == hipSuccess)
+            ctx->stats.ms_kernel[ctx->ev_pool[i].cls] += ms;
+    }
+    ctx->ev_used = 0;
+}
+
+namespace {
+
+template <typename T>
+int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
+{
+    void *q = nullptr;
+    uint64_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        ctx->last_hip_error = (int)e;
+        return KISS_HIP_E_NOMEM;
+    }
+    ctx->ws_bytes += bytes;
+    *p = reinterpret_cast<T *>(q);
+    return KISS_HIP_OK;
+}
+
+void free_all(kiss_hip_ctx *ctx)
+{
+    void *ptrs[] = {ctx->pk,   ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->lms_pos,  ctx->keyA,
+                    ctx->keyB, ctx->posA,    ctx->posB,     ctx->segA,     ctx->segB,     ctx->slotA,
+                    ctx->slotB, ctx->flags,  ctx->lms_sorted_far, ctx->lmsP, ctx->lmsC,   ctx->tile_hist,
+                    ctx->scan_tmp, ctx->CTX, ctx->ind_counts, ctx->d_small, ctx->near_idx, ctx->near_fin,
+                    ctx->near_pos};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (auto &e : ctx->ev_pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+}
+
+int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo, uint32_t *d_SA, void *stream)
+{
+    if (!ctx || !d_SA || (n && !d_S)) return KISS_HIP_E_INVALID;
+    if (n > KISS_HIP_MAX_N || n > ctx->max_n) return KISS_HIP_E_INVALID;
+    if (algo != KISS_HIP_ALGO_PARALLEL_SORTING && algo != KISS_HIP_ALGO_PREFIX_DOUBLING) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    std::memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n = n;
+    ctx->stats.k = k;
+    ctx->n = n;
+    ctx->m = ctx->m_far = 0;
+    if (n == 0) { // kiss1_core.hpp:237-238
+        KCHECK(hipMemsetAsync(d_SA, 0, sizeof(uint32_t), ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        return KISS_HIP_OK;
+    }
+    // effective comparison depth: 125 * (k/125 + 1) full-stride blocks (kiss1_core.hpp:95-118);
+    // k >= n compares to the end of the text = exact suffix order
+    uint64_t depth;
+    if ((uint64_t)k >= n) depth = 0;
+    else depth = (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
+    if (algo == KISS_HIP_ALGO_PREFIX_DOUBLING && depth != 0) {
+        // KISS2 with bounded k is not a function of its input (thread-count dependent ties); only the
+        // exact-order case is defined.
+        return KISS_HIP_E_UNSUPPORTED;
+    }
+    ctx->stats.depth = (uint32_t)(depth > 0xFFFFFFFFull ? 0xFFFFFFFFull : depth);
+
+    hipEvent_t ev[6];
+    for (auto &e : ev) KCHECK(hipEventCreate(&e));
+    int rc = KISS_HIP_OK;
+    do {
+        (void)hipEventRecord(ev[0], ctx->stream);
+        if ((rc = kiss_pack_text(ctx, d_S, n))) break;
+        (void)hipEventRecord(ev[1], ctx->stream);
+        if ((rc = kiss_classify(ctx, n, depth))) break;
+        (void)hipEventRecord(ev[2], ctx->stream);
+        if ((rc = kiss_lms_sort(ctx, n, k, depth))) break;
+        (void)hipEventRecord(ev[3], ctx->stream);
+        if ((rc = kiss_place_lms(ctx, n, k, depth))) break;
+        (void)hipEventRecord(ev[4], ctx->stream);
+        if ((rc = kiss_induce(ctx, n, d_SA))) break;
+        (void)hipEventRecord(ev[5], ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
+        float ms[5];
+        for (int i = 0; i < 5; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+        ctx->stats.ms_pack = ms[0];
+        ctx->stats.ms_classify = ms[1];
+        ctx->stats.ms_lms_sort = ms[2];
+        ctx->stats.ms_place = ms[3];
+        ctx->stats.ms_induce = ms[4];
+        (void)hipEventElapsedTime(&ctx->stats.ms_total, ev[0], ev[5]);
+    } while (0);
+    if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
+    ctx->stats.m = ctx->m;
+    ktimer_collect(ctx);
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int kiss_hip_version(void) { return KISS_HIP_VERSION; }
+
+const char *kiss_hip_strerror(int status)
+{
+    switch (status) {
+    case KISS_HIP_OK: return "ok";
+    case KISS_HIP_E_INVALID: return "invalid argument";
+    case KISS_HIP_E_NO_DEVICE: return "no usable HIP device";
+    case KISS_HIP_E_HIP: return "HIP runtime error";
+    case KISS_HIP_E_NOMEM: return "out of memory";
+    case KISS_HIP_E_UNSUPPORTED: return "request outside the implemented range";
+    case KISS_HIP_E_INTERNAL: return "internal invariant violated";
+    default: return "unknown status";
+    }
+}
+
+int kiss_hip_device_count(int *count)
+{
+    if (!count) return KISS_HIP_E_INVALID;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        *count = 0;
+        return KISS_HIP_E_NO_DEVICE;
+    }
+    *count = c;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
+{
+    if (!out || max_n > KISS_HIP_MAX_N) return KISS_HIP_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return KISS_HIP_E_NO_DEVICE;
+    kiss_hip_ctx *ctx = new (std::nothrow) kiss_hip_ctx();
+    if (!ctx) return KISS_HIP_E_NOMEM;
+    ctx->device = device;
+    ctx->max_n = max_n;
+    int rc = KISS_HIP_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
+        ctx->stream = ctx->own_stream;
+        const uint64_t words = max_n / 32 + 8;
+        ctx->pk_words = words;
+        ctx->n_tiles_cap = words / 256 + 2;
+        ctx->m_cap = max_n / 2 + 2;
+        const uint64_t radix_tiles = ctx->m_cap / 4096 + 2;
+        ctx->tile_hist_cap = 256 * radix_tiles + 8;
+        ctx->ind_tiles_cap = 4 * ((max_n + 1) / 2048 + 2) + 2;
+        uint64_t biggest_scan = ctx->m_cap;
+        if (ctx->tile_hist_cap > biggest_scan) biggest_scan = ctx->tile_hist_cap;
+        if (ctx->ind_tiles_cap > biggest_scan) biggest_scan = ctx->ind_tiles_cap;
+        if (ctx->n_tiles_cap > biggest_scan) biggest_scan = ctx->n_tiles_cap;
+        ctx->scan_tmp_cap = biggest_scan / 4096 + 16;
+        ctx->near_cap = 65536;
+#define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
+        ALLOC(pk, words);
+        ALLOC(tile_gp, ctx->n_tiles_cap);
+        ALLOC(tile_cnt, ctx->n_tiles_cap);
+        ALLOC(d_counts, 16);
+        ALLOC(lms_pos, ctx->m_cap);
+        ALLOC(keyA, ctx->m_cap);
+        ALLOC(keyB, ctx->m_cap);
+        ALLOC(posA, ctx->m_cap);
+        ALLOC(posB, ctx->m_cap);
+        ALLOC(segA, ctx->m_cap);
+        ALLOC(segB, ctx->m_cap);
+        ALLOC(slotA, ctx->m_cap);
+        ALLOC(slotB, ctx->m_cap);
+        ALLOC(flags, 2 * ctx->m_cap);
+        ALLOC(lms_sorted_far, ctx->m_cap);
+        ALLOC(lmsP, ctx->m_cap);
+        ALLOC(lmsC, ctx->m_cap);
+        ALLOC(tile_hist, ctx->tile_hist_cap);
+        ALLOC(scan_tmp, ctx->scan_tmp_cap);
+        ALLOC(CTX, max_n + 2);
+        ALLOC(ind_counts, ctx->ind_tiles_cap);
+        ALLOC(d_small, 64);
+        ALLOC(near_idx, ctx->near_cap);
+        ALLOC(near_fin, ctx->near_cap);
+        ALLOC(near_pos, ctx->near_cap);
+#undef ALLOC
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            rc = KISS_HIP_E_NOMEM;
+            break;
+        }
+        ctx->h_pinned = reinterpret_cast<uint32_t *>(hp);
+    } while (0);
+    if (rc != KISS_HIP_OK) {
+        free_all(ctx);
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_destroy(kiss_hip_ctx *ctx)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    free_all(ctx);
+    delete ctx;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_set_profiling(kiss_hip_ctx *ctx, int enabled)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    ctx->profiling = enabled != 0;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_last_hip_error(const kiss_hip_ctx *ctx, const char **msg)
+{
+    if (!ctx) return 0;
+    if (msg) *msg = hipGetErrorString((hipError_t)ctx->last_hip_error);
+    return ctx->last_hip_error;
+}
+
+int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out)
+{
+    if (!ctx || !out) return KISS_HIP_E_INVALID;
+    *out = ctx->stats;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes)
+{
+    if (!ctx || !bytes) return KISS_HIP_E_INVALID;
+    *bytes = ctx->ws_bytes;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo,
+                                         uint32_t *d_SA, void *stream)
+{
+    return sort_dev(ctx, d_S, n, k, algo, d_SA, stream);
+}
+
+int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, int algo,
+                                     uint32_t *SA)
+{
+    if (!ctx || !SA || (n && !S)) return KISS_HIP_E_INVALID;
+    if (n > ctx->max_n) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    uint8_t *d_S = nullptr;
+    uint32_t *d_SA = nullptr;
+    int rc = KISS_HIP_OK;
+    do {
+        hipError_t e = hipMalloc((void **)&d_S, n ? n : 1);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_SA, (n + 1) * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_NOMEM;
+            break;
+        }
+        if (n) e = hipMemcpy(d_S, S, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
+        if ((rc = sort_dev(ctx, d_S, n, k, algo, d_SA, nullptr))) break;
+        e = hipMemcpy(SA, d_SA, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_HIP;
+        }
+    } while (0);
+    if (d_S) (void)hipFree(d_S);
+    if (d_SA) (void)hipFree(d_SA);
+    return rc;
+}
+
+int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device)
+{
+    if (!SA || (n && !S)) return KISS_HIP_E_INVALID;
+    if (n == 0) { // kiss1_core.hpp:237-238: no device work at all
+        SA[0] = 0;
+        return KISS_HIP_OK;
+    }
+    kiss_hip_ctx *ctx = nullptr;
+    int rc = kiss_hip_ctx_create(&ctx, device, n);
+    if (rc) return rc;
+    rc = kiss_hip_ctx_suffix_sort_dna_u32(ctx, S, n, k, algo, SA);
+    kiss_hip_ctx_destroy(ctx);
+    return rc;
+}
+
+int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, uint32_t *lms_sorted, uint64_t *counts)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    if (lms_ascending && ctx->m)
+        KCHECK(hipMemcpy(lms_ascending, ctx->lms_pos, ctx->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (lms_sorted && ctx->m)
+        KCHECK(hipMemcpy(lms_sorted, ctx->lmsP, ctx->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (counts)
+        for (int i = 0; i < 12; i++) counts[i] = ctx->counts[i];
+    return KISS_HIP_OK;
+}
+
+} // extern "C"

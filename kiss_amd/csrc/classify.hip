@@ -1,0 +1,354 @@
+// classify.hip -- 2-bit packing and get_lms on the GPU.
+//
+// Restates the *result* of get_lms (reference include/biovoltron/algo/sort/kiss_common.hpp:483-579):
+// the ascending list of LMS positions and the per-character histograms
+// (count[c], S-type count, LMS count), not its thread-chunk structure.
+//
+// Types are computed bit-parallel on the packed text.  One thread owns one 64-bit
+// word (32 bases).  For adjacent bases the word gives lt/eq masks; the suffix type
+//     S(i) = lt(i) | (eq(i) & S(i+1))
+// is a carry chain running from later bases (low bits) to earlier ones (high bits),
+// evaluated with ONE 64-bit addition per word, one ballot+addition per wave, and a
+// generate/propagate fold across waves and 256-word tiles (three launches:
+// tile summaries -> serial-free scan of summaries -> count / emit).
+#include "kiss_internal.hpp"
+
+namespace {
+
+constexpr uint64_t HI = 0xAAAAAAAAAAAAAAAAull;
+constexpr uint64_t LO = 0x5555555555555555ull;
+constexpr int CL_THREADS = 256; // words per tile
+
+// ---- 2-bit packing --------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack(const uint8_t *__restrict__ S, uint64_t n, uint64_t *__restrict__ pk,
+                                              uint64_t words)
+{
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint64_t base = w * 32;
+    uint64_t out = 0;
+    if (base + 32 <= n && ((reinterpret_cast<uintptr_t>(S + base) & 15u) == 0)) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(S + base);
+        uint4 v0 = p[0], v1 = p[1];
+        uint32_t q[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            uint32_t u = q[t] & 0x03030303u; // bytes b0..b3 (b0 = lowest = earliest base)
+            // -> 8 bits: b0 b1 b2 b3 from high to low
+            uint32_t r = ((u & 0x3u) << 6) | (((u >> 8) & 0x3u) << 4) | (((u >> 16) & 0x3u) << 2) | ((u >> 24) & 0x3u);
+            out |= (uint64_t)r << (56 - 8 * t);
+        }
+    } else {
+        for (int j = 0; j < 32; j++) {
+            uint64_t i = base + j;
+            uint64_t c = (i < n) ? (uint64_t)(S[i] & 3u) : 0ull;
+            out |= c << (62 - 2 * j);
+        }
+    }
+    pk[w] = out;
+}
+
+// ---- per-word masks ---------------------------------------------------------------
+struct WordMasks {
+    uint64_t x;  // the packed word
+    uint64_t A;  // adder operand (lt|eq at HI positions, all LO bits set)
+    uint64_t B;  // adder operand (lt at HI positions)
+};
+
+__device__ __forceinline__ WordMasks word_masks(const uint64_t *__restrict__ pk, uint64_t w, uint64_t n)
+{
+    WordMasks m;
+    uint64_t x = pk[w];
+    uint64_t nx = pk[w + 1];
+    uint64_t y = (x << 2) | (nx >> 62); // field j of y = base 32w+j+1
+    uint64_t d = x ^ y;
+    uint64_t eqh = ~d & HI;
+    uint64_t eql = ~d & LO;
+    uint64_t eq = eqh & (eql << 1);
+    uint64_t xy = ~x & y;
+    uint64_t lt = (xy & HI) | (eqh & ((xy & LO) << 1));
+    // only bases i < n-1 take part (base n-1 is L-type: the sentinel is smaller)
+    int64_t rem = (int64_t)(n - 1) - (int64_t)(w * 32);
+    uint64_t vmask = rem >= 32 ? ~0ull : (rem <= 0 ? 0ull : (~0ull << (64 - 2 * rem)));
+    lt &= vmask;
+    eq &= vmask;
+    m.x = x;
+    m.A = lt | eq | LO;
+    m.B = lt;
+    return m;
+}
+
+// carry-out of the word's chain for a given carry-in; *sum receives A+B+cin (low 64 bits)
+__device__ __forceinline__ uint32_t word_carry(uint64_t A, uint64_t B, uint32_t cin, uint64_t *sum)
+{
+    uint64_t s = A + B;
+    uint32_t c1 = s < A;
+    uint64_t s2 = s + cin;
+    uint32_t c2 = s2 < s;
+    *sum = s2;
+    return c1 | c2;
+}
+
+// wave-level fold.  G/P per lane (lane = word, higher lane = later text).  Returns this lane's carry-in
+// given the carry-in of the whole wave; *wave_cout receives the wave's carry-out.
+__device__ __forceinline__ uint32_t wave_carry(uint32_t G, uint32_t P, uint32_t wave_cin, uint32_t *wave_cout)
+{
+    uint64_t gm = __ballot(G != 0);
+    uint64_t pm = __ballot(P != 0);
+    uint64_t rg = __brevll(gm), rp = __brevll(pm); // bit b = lane 63-b : carries now run low -> high
+    uint64_t a = rg | rp, b = rg;
+    uint64_t s = a + b;
+    uint32_t c1 = s < a;
+    uint64_t s2 = s + wave_cin;
+    uint32_t c2 = s2 < s;
+    *wave_cout = c1 | c2;
+    uint64_t cins = s2 ^ a ^ b; // bit b = carry into bit b
+    return (uint32_t)(cins >> (63u - lane_id())) & 1u;
+}
+
+// Computes, for the calling thread's word, the S-type mask (bit 62-2j = type of base 32w+j is S)
+// given the carry-in of the tile.  lds: 8 x u32.  All 256 threads must call.
+__device__ __forceinline__ uint64_t tile_types(const WordMasks &m, uint32_t tile_cin, uint32_t *lds)
+{
+    const int wave = threadIdx.x >> 6;
+    uint64_t sum;
+    uint32_t c0 = word_carry(m.A, m.B, 0, &sum);
+    uint32_t c1 = word_carry(m.A, m.B, 1, &sum);
+    uint32_t G = c0, P = c1 & ~c0;
+    uint32_t wc0, wc1;
+    (void)wave_carry(G, P, 0, &wc0);
+    (void)wave_carry(G, P, 1, &wc1);
+    if (lane_id() == 0) {
+        lds[wave * 2 + 0] = wc0;
+        lds[wave * 2 + 1] = wc1 & ~wc0;
+    }
+    __syncthreads();
+    uint32_t c = tile_cin;
+    for (int w = CL_THREADS / 64 - 1; w > wave; w--) c = lds[w * 2] | (lds[w * 2 + 1] & c);
+    uint32_t dummy;
+    uint32_t cin = wave_carry(G, P, c, &dummy);
+    uint32_t cout = word_carry(m.A, m.B, cin, &sum);
+    __syncthreads();
+    return ((~sum & LO) >> 2) | ((uint64_t)cout << 62);
+}
+
+// S[i-1] > S[i] for every field (at HI positions); px = previous word (0 for w == 0)
+__device__ __forceinline__ uint64_t gt_prev_mask(uint64_t x, uint64_t px)
+{
+    uint64_t z = (x >> 2) | (px << 62);
+    uint64_t dz = z ^ x;
+    uint64_t eqh = ~dz & HI;
+    uint64_t zx = z & ~x;
+    return (zx & HI) | (eqh & ((zx & LO) << 1));
+}
+
+// ---- kernel 1: generate/propagate summary of each 256-word tile ----------------------
+__global__ __launch_bounds__(CL_THREADS) void k_tile_gp(const uint64_t *__restrict__ pk, uint64_t n, uint64_t words,
+                                                       uint32_t *__restrict__ tile_gp)
+{
+    __shared__ uint32_t lds[8];
+    uint64_t w = (uint64_t)blockIdx.x * CL_THREADS + threadIdx.x;
+    WordMasks m;
+    if (w < words) m = word_masks(pk, w, n);
+    else { m.x = 0; m.A = LO; m.B = 0; }
+    uint64_t sum;
+    uint32_t c0 = word_carry(m.A, m.B, 0, &sum);
+    uint32_t c1 = word_carry(m.A, m.B, 1, &sum);
+    uint32_t wc0, wc1;
+    (void)wave_carry(c0, c1 & ~c0, 0, &wc0);
+    (void)wave_carry(c0, c1 & ~c0, 1, &wc1);
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+        lds[wave * 2 + 0] = wc0;
+        lds[wave * 2 + 1] = wc1 & ~wc0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 1;
+        for (int v = CL_THREADS / 64 - 1; v >= 0; v--) {
+            a = lds[v * 2] | (lds[v * 2 + 1] & a);
+            b = lds[v * 2] | (lds[v * 2 + 1] & b);
+        }
+        tile_gp[blockIdx.x] = a | ((b & ~a) << 1);
+    }
+}
+
+// ---- kernel 2: turn tile (G,P) into tile carry-ins (right-to-left fold), single workgroup -----
+__global__ __launch_bounds__(1024) void k_tile_cin(uint32_t *__restrict__ tile_gp, uint64_t tiles)
+{
+    __shared__ uint32_t sg[1024], sp[1024], scin[1024];
+    const uint64_t chunk = (tiles + 1023) / 1024;
+    const uint64_t beg = (uint64_t)threadIdx.x * chunk;
+    const uint64_t end = beg + chunk < tiles ? beg + chunk : tiles;
+    uint32_t a = 0, b = 1; // chunk carry-out for cin = 0 / 1
+    for (uint64_t t = end; t > beg; t--) {
+        uint32_t gp = tile_gp[t - 1];
+        uint32_t g = gp & 1u, p = (gp >> 1) & 1u;
+        a = g | (p & a);
+        b = g | (p & b);
+    }
+    if (beg >= end) { a = 0; b = 1; }
+    sg[threadIdx.x] = a;
+    sp[threadIdx.x] = b & ~a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int i = 1023; i >= 0; i--) {
+            scin[i] = c;
+            c = sg[i] | (sp[i] & c);
+        }
+    }
+    __syncthreads();
+    uint32_t c = scin[threadIdx.x];
+    for (uint64_t t = end; t > beg; t--) {
+        uint32_t gp = tile_gp[t - 1];
+        tile_gp[t - 1] = c;
+        c = (gp & 1u) | (((gp >> 1) & 1u) & c);
+    }
+}
+
+// ---- kernel 3/4: count (histograms + per-tile LMS count) and emit (positions + first keys) ------
+template <bool EMIT>
+__global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restrict__ pk, uint64_t n, uint64_t words,
+                                                        uint64_t tiles, const uint32_t *__restrict__ tile_cin,
+                                                        uint32_t *__restrict__ tile_cnt, // count: out; emit: offsets in
+                                                        uint32_t *__restrict__ d_counts, uint64_t far_limit,
+                                                        uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key)
+{
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t wsum[CL_THREADS / 64 + 1];
+    uint32_t acc[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) acc[i] = 0;
+
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint64_t w = tile * CL_THREADS + threadIdx.x;
+        WordMasks m;
+        if (w < words) m = word_masks(pk, w, n);
+        else { m.x = 0; m.A = LO; m.B = 0; }
+        uint64_t T = tile_types(m, tile_cin[tile], lds);
+        uint64_t px = (w > 0 && w <= words) ? pk[w - 1] : 0ull;
+        uint64_t lmsmask = T & (gt_prev_mask(m.x, px) >> 1);
+        if (w >= words) lmsmask = 0;
+        uint32_t cnt = __popcll(lmsmask);
+        if (!EMIT) {
+            // histograms
+            int64_t vn = (int64_t)n - (int64_t)(w * 32);
+            uint64_t V = (w >= words || vn <= 0) ? 0ull : (vn >= 32 ? LO : (LO & (~0ull << (64 - 2 * vn))));
+            uint64_t hi = (m.x >> 1) & LO, lo = m.x & LO;
+            uint64_t is[4] = {~hi & ~lo & LO, ~hi & lo, hi & ~lo, hi & lo};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                acc[c] += __popcll(is[c] & V);
+                acc[4 + c] += __popcll(is[c] & T);
+                acc[8 + c] += __popcll(is[c] & lmsmask);
+            }
+            // far LMS: position i = 32w + j with i <= far_limit  (far_limit = n - D, or ~0 for all)
+            uint64_t farmask = lmsmask;
+            if (far_limit != ~0ull) {
+                int64_t fj = (int64_t)far_limit - (int64_t)(w * 32); // fields j <= fj are far
+                farmask = fj >= 31 ? lmsmask : (fj < 0 ? 0ull : (lmsmask & (~0ull << (62 - 2 * fj))));
+            }
+            acc[12] += __popcll(farmask);
+            // per-tile LMS count
+            uint32_t v = cnt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane_id() == 0) wsum[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t t = 0;
+                for (int i = 0; i < CL_THREADS / 64; i++) t += wsum[i];
+                tile_cnt[tile] = t;
+            }
+            __syncthreads();
+        } else {
+            // exclusive scan of cnt over the tile
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(inc, d, 64);
+                if ((int)lane_id() >= d) inc += o;
+            }
+            if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            uint32_t off = tile_cnt[tile];
+            for (int i = 0; i < (int)(threadIdx.x >> 6); i++) off += wsum[i];
+            off += inc - cnt;
+            uint64_t mm = lmsmask;
+            while (mm) {
+                int bit = 63 - __clzll(mm); // highest set bit first = smallest position
+                mm &= ~(1ull << bit);
+                uint32_t j = (uint32_t)(62 - bit) >> 1;
+                uint64_t pos = w * 32 + j;
+                lms_pos[off] = (uint32_t)pos;
+                lms_key[off] = kiss_key32(pk, pos);
+                off++;
+            }
+            __syncthreads();
+        }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            uint32_t v = acc[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            if (lane_id() == 0 && v) atomicAdd(&d_counts[i], v);
+        }
+    }
+}
+
+} // namespace
+
+int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n)
+{
+    const uint64_t words = div_up(n, 32) + 4; // spare zero words: key loads may touch w+1 past the end
+    if (words > ctx->pk_words) return KISS_HIP_E_INTERNAL;
+    KTimer t(ctx, KISS_HIP_K_PACK, n);
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)div_up(words, 256)), dim3(256), 0, ctx->stream, d_S, n, ctx->pk, words);
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}
+
+int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
+{
+    const uint64_t words = div_up(n, 32);
+    const uint64_t tiles = div_up(words, CL_THREADS);
+    if (tiles > ctx->n_tiles_cap) return KISS_HIP_E_INTERNAL;
+    // far LMS suffixes: p + depth <= n  (all of them when unbounded)
+    uint64_t far_limit = ~0ull;
+    bool none_far = false;
+    if (depth != 0) {
+        if (depth > n) none_far = true;
+        else far_limit = n - depth;
+    }
+    KCHECK(hipMemsetAsync(ctx->d_counts, 0, 16 * sizeof(uint32_t), ctx->stream));
+    {
+        KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
+        hipLaunchKernelGGL(k_tile_gp, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words,
+                           ctx->tile_gp);
+        hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_gp, tiles);
+        unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
+        hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
+                           ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, (uint32_t *)nullptr,
+                           (uint64_t *)nullptr);
+        KCHECK(hipGetLastError());
+    }
+    KTRY(kiss_scan_u32(ctx, ctx->tile_cnt, ctx->tile_cnt, tiles));
+    KCHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_counts, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 12; i++) ctx->counts[i] = ctx->h_pinned[i];
+    uint64_t m = (uint64_t)ctx->h_pinned[8] + ctx->h_pinned[9] + ctx->h_pinned[10] + ctx->h_pinned[11];
+    ctx->m = m;
+    ctx->m_far = none_far ? 0 : ctx->h_pinned[12];
+    if (m > ctx->m_cap) return KISS_HIP_E_INTERNAL;
+    if (m > 0) {
+        KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
+        hipLaunchKernelGGL(k_classify<true>, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
+                           words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, ctx->lms_pos,
+                           ctx->keyA);
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}

@@ -1,0 +1,146 @@
+// kiss_internal.hpp -- shared declarations of libkiss_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "../../include/kiss_hip.h"
+
+#define KISS_EMPTY_CTX 1u      // context word with no bases left (marker bit only)
+#define KISS_CTX_BASES 15u     // bases carried in a 32-bit context word
+#define KISS_STRIDE 125u       // KISS1_SPLIT_SORT_STRIDE_DNA, algo/sort/constant.hpp:29
+
+// ---- error plumbing -----------------------------------------------------------
+struct kiss_hip_ctx;
+#define KCHECK(call)                                   \
+    do {                                               \
+        hipError_t e__ = (call);                       \
+        if (e__ != hipSuccess) {                       \
+            ctx->last_hip_error = (int)e__;            \
+            return (e__ == hipErrorOutOfMemory) ? KISS_HIP_E_NOMEM : KISS_HIP_E_HIP; \
+        }                                              \
+    } while (0)
+#define KTRY(expr)                 \
+    do {                           \
+        int s__ = (expr);          \
+        if (s__ != KISS_HIP_OK) return s__; \
+    } while (0)
+
+// ---- device workspace -----------------------------------------------------------
+struct kiss_hip_ctx {
+    int device = 0;
+    int last_hip_error = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream of the current call
+    uint64_t max_n = 0;
+    uint64_t m_cap = 0;            // capacity of LMS arrays
+    uint64_t ws_bytes = 0;
+
+    // text
+    uint64_t *pk = nullptr;        // 2-bit packed text, base i at bits [63-2(i%32), 62-2(i%32)] of word i/32
+    uint64_t pk_words = 0;
+    // classification scratch
+    uint32_t *tile_gp = nullptr;   // per 256-word tile: bit0 = G, bit1 = P  -> later: carry-in of the tile
+    uint32_t *tile_cnt = nullptr;  // per tile LMS count -> exclusive offsets
+    uint64_t n_tiles_cap = 0;
+    uint32_t *d_counts = nullptr;  // 16 x u32: cnt[4], cntS[4], cntLMS[4], far_lms, spare
+    // LMS arrays
+    uint32_t *lms_pos = nullptr;   // ascending LMS positions (kept for stage output)
+    uint64_t *keyA = nullptr, *keyB = nullptr;
+    uint32_t *posA = nullptr, *posB = nullptr;
+    uint32_t *segA = nullptr, *segB = nullptr;
+    uint32_t *slotA = nullptr, *slotB = nullptr;
+    uint64_t *flags = nullptr;     // per active item: (survivor << 32) | surviving-head, then its exclusive scan
+    uint32_t *lms_sorted_far = nullptr; // far LMS suffixes in k-order
+    uint32_t *lmsP = nullptr;      // all LMS suffixes in k-order (sentinel excluded)
+    uint32_t *lmsC = nullptr;      // their context words
+    // radix / scan scratch
+    uint32_t *tile_hist = nullptr; // 256 x tiles (+1)
+    uint64_t tile_hist_cap = 0;
+    uint64_t *scan_tmp = nullptr;  // block sums for scans
+    uint64_t scan_tmp_cap = 0;
+    // induce
+    uint32_t *CTX = nullptr;       // context words parallel to SA (n+1)
+    uint32_t *ind_counts = nullptr;// 4 x tiles + 1
+    uint64_t ind_tiles_cap = 0;
+    uint32_t *d_small = nullptr;   // small scratch (64 u32) for single-workgroup kernels
+    uint32_t *h_pinned = nullptr;  // 64 u32 pinned host scratch
+    // near-end
+    uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr;
+    uint64_t near_cap = 0;
+
+    // state of the last call (for stage outputs / stats)
+    uint64_t n = 0, m = 0, m_far = 0;
+    uint64_t counts[12] = {0};
+    kiss_hip_stats stats{};
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int cls; };
+    std::vector<Ev> ev_pool;
+    size_t ev_used = 0;
+};
+
+// RAII-less helper: times one kernel class when profiling is on
+struct KTimer {
+    kiss_hip_ctx *ctx;
+    int idx;
+    KTimer(kiss_hip_ctx *c, int cls, uint64_t items);
+    ~KTimer();
+};
+void ktimer_collect(kiss_hip_ctx *ctx);
+
+static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ---- stages (host drivers) -------------------------------------------------------
+int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
+// classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
+int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*/);
+// exclusive scans (in place allowed: out may equal in)
+int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count);
+int kiss_scan_u64(kiss_hip_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t count);
+// stable LSD radix sort of (key64[, seg32], pos32) tuples; bits [key_lo_bit,64) of key then seg_bits of seg.
+// Buffers ping-pong; on return *in_is_result tells which pair holds the sorted data (true = the A buffers).
+struct RadixBufs {
+    uint64_t *key[2];
+    uint32_t *seg[2]; // may be null when seg_bits == 0
+    uint32_t *pos[2];
+};
+int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
+// k-ordered LMS sort of the far suffixes -> ctx->lms_sorted_far
+int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
+// near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
+int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
+// induced sort sweeps -> d_SA
+int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA);
+
+// ---- device helpers ----------------------------------------------------------------
+#ifdef __HIPCC__
+// 32 bases starting at base index p (zero = 'A' padding past the end; pk has >= 2 spare zero words)
+__device__ __forceinline__ uint64_t kiss_key32(const uint64_t *__restrict__ pk, uint64_t p)
+{
+    uint64_t w = p >> 5;
+    uint32_t s = (uint32_t)(p & 31u) * 2u;
+    uint64_t a = pk[w];
+    uint64_t b = pk[w + 1];
+    return s ? ((a << s) | (b >> (64u - s))) : a;
+}
+__device__ __forceinline__ uint32_t kiss_base(const uint64_t *__restrict__ pk, uint64_t p)
+{
+    return (uint32_t)(pk[p >> 5] >> (62u - 2u * (uint32_t)(p & 31u))) & 3u;
+}
+// context word of position v: bases v-1 (bits 1:0), v-2 (bits 3:2), ... up to 15 bases, marker bit above
+__device__ __forceinline__ uint32_t kiss_load_ctx(const uint64_t *__restrict__ pk, uint64_t v)
+{
+    if (v >= KISS_CTX_BASES) {
+        uint64_t k = kiss_key32(pk, v - KISS_CTX_BASES);
+        return (uint32_t)(k >> (64u - 2u * KISS_CTX_BASES)) | (1u << (2u * KISS_CTX_BASES));
+    }
+    if (v == 0) return KISS_EMPTY_CTX;
+    uint64_t w0 = pk[0];
+    return (uint32_t)(w0 >> (64u - 2u * (uint32_t)v)) | (1u << (2u * (uint32_t)v));
+}
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63u)) - 1ull;
+}
+#endif

@@ -1,0 +1,185 @@
+// place.hip -- finishes the k-ordered LMS order and attaches context words.
+//
+// 1. Near-end rule.  LMS suffixes with fewer than D bases left are compared by the reference
+//    comparator's scalar tail (include/biovoltron/algo/sort/kiss1_core.hpp:120-134): at most k bases, then
+//    position; a suffix that runs off the text is smaller.  There are < D/2 of them.  Each is ranked
+//    against the sorted far list by binary search with the full comparator (10-mer bucket with 'A'
+//    padding, kiss1_core.hpp:41-83 + structs.hpp:175-184, then cmp), and among themselves pairwise.
+//    Every far suffix precedes every near-end suffix in text position, so cmp(far, near) is monotone
+//    over the far list and the insertion point is unique.
+// 2. Merge far + near-end into the final list lmsP and gather the context word (the <= 15 bases that
+//    precede each suffix) the induction sweeps consume instead of random text reads.
+#include "kiss_internal.hpp"
+
+namespace {
+
+constexpr int PL_THREADS = 256;
+
+// compare len bases at i and j (both ranges inside the text): <0, 0, >0
+__device__ int cmp_bases(const uint64_t *__restrict__ pk, uint64_t i, uint64_t j, uint64_t len)
+{
+    while (len >= 32) {
+        uint64_t a = kiss_key32(pk, i), b = kiss_key32(pk, j);
+        if (a != b) return a < b ? -1 : 1;
+        i += 32;
+        j += 32;
+        len -= 32;
+    }
+    if (len) {
+        uint64_t mask = ~0ull << (64 - 2 * len);
+        uint64_t a = kiss_key32(pk, i) & mask, b = kiss_key32(pk, j) & mask;
+        if (a != b) return a < b ? -1 : 1;
+    }
+    return 0;
+}
+
+// the reference comparator (kiss1_core.hpp:94-135) on the packed text
+__device__ bool lms_less(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k, uint64_t i, uint64_t j)
+{
+    uint64_t sl = 0;
+    while (sl <= k && i + KISS_STRIDE <= n && j + KISS_STRIDE <= n) {
+        int r = cmp_bases(pk, i, j, KISS_STRIDE);
+        if (r) return r < 0;
+        sl += KISS_STRIDE;
+        i += KISS_STRIDE;
+        j += KISS_STRIDE;
+    }
+    // scalar tail: at most k bases in total, stop at the end of either suffix
+    uint64_t room = k > sl ? k - sl : 0;
+    uint64_t li = n - i, lj = n - j;
+    uint64_t len = room;
+    if (li < len) len = li;
+    if (lj < len) len = lj;
+    int r = cmp_bases(pk, i, j, len);
+    if (r) return r < 0;
+    sl += len;
+    i += len;
+    j += len;
+    if (sl >= k) return i < j;
+    return i == n;
+}
+
+__device__ __forceinline__ uint32_t prefix10(const uint64_t *__restrict__ pk, uint64_t n, uint64_t p)
+{
+    if (p >= n) return 0;
+    return (uint32_t)(kiss_key32(pk, p) >> 44); // 10 bases; zero padding past the end
+}
+
+__device__ bool lms_less_full(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k, uint64_t i, uint64_t j)
+{
+    uint32_t a = prefix10(pk, n, i), b = prefix10(pk, n, j);
+    if (a != b) return a < b;
+    return lms_less(pk, n, k, i, j);
+}
+
+// near_idx[e] = number of far suffixes that sort before near-end suffix e
+__global__ __launch_bounds__(PL_THREADS) void k_near_rank(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k,
+                                                         const uint32_t *__restrict__ far_sorted, uint64_t m_far,
+                                                         const uint32_t *__restrict__ near_pos, uint32_t E,
+                                                         uint32_t *__restrict__ near_idx)
+{
+    uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    uint64_t pe = near_pos[e];
+    uint64_t lo = 0, hi = m_far;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (lms_less_full(pk, n, k, far_sorted[mid], pe)) lo = mid + 1;
+        else hi = mid;
+    }
+    near_idx[e] = (uint32_t)lo;
+}
+
+// near_fin[e] = final index of near-end suffix e in the merged list
+__global__ __launch_bounds__(PL_THREADS) void k_near_order(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k,
+                                                          const uint32_t *__restrict__ near_pos,
+                                                          const uint32_t *__restrict__ near_idx, uint32_t E,
+                                                          uint32_t *__restrict__ near_fin)
+{
+    uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    uint64_t pe = near_pos[e];
+    uint32_t ie = near_idx[e];
+    uint32_t r = 0;
+    for (uint32_t f = 0; f < E; f++) {
+        if (f == e) continue;
+        uint32_t jf = near_idx[f];
+        if (jf < ie || (jf == ie && lms_less_full(pk, n, k, near_pos[f], pe))) r++;
+    }
+    near_fin[e] = ie + r;
+}
+
+// merged list + context words.  near_sidx: insertion indexes sorted ascending (E entries)
+__global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__restrict__ pk,
+                                                         const uint32_t *__restrict__ far_sorted, uint64_t m_far,
+                                                         const uint32_t *__restrict__ near_sidx, uint32_t E,
+                                                         uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC)
+{
+    uint64_t i = (uint64_t)blockIdx.x * PL_THREADS + threadIdx.x;
+    if (i >= m_far) return;
+    // shift = #{e : near_idx[e] <= i}
+    uint32_t lo = 0, hi = E;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (near_sidx[mid] <= i) lo = mid + 1;
+        else hi = mid;
+    }
+    uint32_t x = far_sorted[i];
+    lmsP[i + lo] = x;
+    lmsC[i + lo] = kiss_load_ctx(pk, x);
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__restrict__ pk,
+                                                          const uint32_t *__restrict__ near_pos,
+                                                          const uint32_t *__restrict__ near_fin, uint32_t E,
+                                                          uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC)
+{
+    uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    uint32_t x = near_pos[e];
+    lmsP[near_fin[e]] = x;
+    lmsC[near_fin[e]] = kiss_load_ctx(pk, x);
+}
+
+} // namespace
+
+#include <algorithm>
+#include <vector>
+
+int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
+{
+    (void)depth;
+    const uint64_t m = ctx->m, m_far = ctx->m_far;
+    const uint64_t E64 = m - m_far;
+    ctx->stats.near_end = E64;
+    if (m == 0) return KISS_HIP_OK;
+    if (E64 > ctx->near_cap) return KISS_HIP_E_UNSUPPORTED;
+    const uint32_t E = (uint32_t)E64;
+    KTimer t(ctx, KISS_HIP_K_PLACE, m);
+    if (E > 0) {
+        const uint32_t *near_pos = ctx->lms_pos + m_far; // ascending list: the near-end suffixes are its tail
+        hipLaunchKernelGGL(k_near_rank, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
+                           ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);
+        hipLaunchKernelGGL(k_near_order, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
+                           ctx->pk, n, (uint64_t)k, near_pos, ctx->near_idx, E, ctx->near_fin);
+        KCHECK(hipGetLastError());
+        // sorted insertion indexes for the merge (E is tiny: sort on the host)
+        std::vector<uint32_t> idx(E);
+        KCHECK(hipMemcpyAsync(idx.data(), ctx->near_idx, E * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        std::sort(idx.begin(), idx.end());
+        KCHECK(hipMemcpyAsync(ctx->near_pos, idx.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream)); // idx goes out of scope
+        if (m_far)
+            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0,
+                               ctx->stream, ctx->pk, ctx->lms_sorted_far, m_far, ctx->near_pos, E, ctx->lmsP,
+                               ctx->lmsC);
+        hipLaunchKernelGGL(k_merge_near, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
+                           ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
+    } else {
+        hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
+                           ctx->pk, ctx->lms_sorted_far, m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP, ctx->lmsC);
+    }
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}

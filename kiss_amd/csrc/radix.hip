@@ -1,0 +1,202 @@
+// radix.hip -- stable LSD radix sort of (key64 [, seg32], pos32) tuples, 8 bits per pass.
+//
+// Per pass: tile histogram -> device-wide exclusive scan of the (digit-major) tile
+// histograms -> scatter.  The scatter ranks items inside a 4096-item tile with
+// wave64 ballots (8 ballots give each lane the set of lanes holding its digit),
+// reorders the tile in LDS so that every digit's items leave as one contiguous,
+// coalesced run, and writes them out.  Item order inside a tile is
+// (wave, round, lane) = memory order, so the sort is stable: equal keys keep the
+// ascending text position order the k-ordered LMS contract needs
+// (reference tie-break `i < j`, include/biovoltron/algo/sort/kiss1_core.hpp:131-133).
+#include "kiss_internal.hpp"
+
+namespace {
+
+constexpr int RX_THREADS = 256;
+constexpr int RX_ITEMS = 16;
+constexpr int RX_WAVES = RX_THREADS / 64;
+constexpr int RX_WAVE_TILE = RX_ITEMS * 64;        // 1024
+constexpr int RX_TILE = RX_THREADS * RX_ITEMS;     // 4096
+
+template <int SRC>
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, uint32_t seg, int shift)
+{
+    return SRC == 0 ? (uint32_t)(key >> shift) & 255u : (seg >> shift) & 255u;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__restrict__ key,
+                                                          const uint32_t *__restrict__ seg, uint64_t count, int shift,
+                                                          uint32_t *__restrict__ tile_hist, uint64_t tiles)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * RX_TILE + (uint64_t)(threadIdx.x >> 6) * RX_WAVE_TILE + lane_id();
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        uint64_t g = base + (uint64_t)j * 64;
+        if (g < count) {
+            uint32_t d = SRC == 0 ? (uint32_t)(key[g] >> shift) & 255u : (seg[g] >> shift) & 255u;
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    tile_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <int SRC, bool HAS_SEG>
+__global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__restrict__ key_in,
+                                                             const uint32_t *__restrict__ seg_in,
+                                                             const uint32_t *__restrict__ pos_in,
+                                                             uint64_t *__restrict__ key_out,
+                                                             uint32_t *__restrict__ seg_out,
+                                                             uint32_t *__restrict__ pos_out, uint64_t count, int shift,
+                                                             const uint32_t *__restrict__ tile_off, uint64_t tiles)
+{
+    __shared__ uint64_t skey[RX_TILE];
+    __shared__ uint32_t spos[RX_TILE];
+    __shared__ uint32_t sseg[HAS_SEG ? RX_TILE : 1];
+    __shared__ uint32_t wcnt[RX_WAVES][256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t wsum[RX_WAVES + 1];
+
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
+    const uint32_t tile_count = (uint32_t)((count - tile_base) < (uint64_t)RX_TILE ? (count - tile_base) : RX_TILE);
+
+#pragma unroll
+    for (int w = 0; w < RX_WAVES; w++) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    uint64_t k[RX_ITEMS];
+    uint32_t s[RX_ITEMS];
+    uint32_t p[RX_ITEMS];
+    uint32_t rk[RX_ITEMS]; // (digit << 16) | rank inside the wave among equal digits; 0xFFFFFFFF = invalid
+
+    const uint32_t wbase = (uint32_t)wave * RX_WAVE_TILE + lane;
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const uint32_t li = wbase + (uint32_t)j * 64;
+        const bool valid = li < tile_count;
+        const uint64_t g = tile_base + li;
+        k[j] = valid ? key_in[g] : 0ull;
+        s[j] = (HAS_SEG && valid) ? seg_in[g] : 0u;
+        p[j] = valid ? pos_in[g] : 0u;
+        const uint32_t d = digit_of<SRC>(k[j], s[j], shift);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bm = __ballot(bit);
+            peers &= bit ? bm : ~bm;
+        }
+        uint32_t old = 0;
+        int leader = 0;
+        if (valid) {
+            leader = __ffsll((unsigned long long)peers) - 1;
+            if ((int)lane == leader) old = atomicAdd(&wcnt[wave][d], (uint32_t)__popcll(peers));
+        }
+        old = __shfl(old, leader, 64);
+        rk[j] = valid ? ((d << 16) | (old + (uint32_t)__popcll(peers & lanemask_lt()))) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+
+    // per digit: totals over waves, exclusive prefix over waves, exclusive scan over digits
+    {
+        const uint32_t d = threadIdx.x;
+        uint32_t c[RX_WAVES];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < RX_WAVES; w++) {
+            c[w] = wcnt[w][d];
+            tot += c[w];
+        }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            uint32_t o = __shfl_up(inc, dd, 64);
+            if ((int)lane >= dd) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t start = inc - tot;
+        for (int w = 0; w < wave; w++) start += wsum[w];
+        gbase[d] = tile_off[(uint64_t)d * tiles + blockIdx.x] - start;
+        uint32_t run = start;
+#pragma unroll
+        for (int w = 0; w < RX_WAVES; w++) {
+            wcnt[w][d] = run;
+            run += c[w];
+        }
+    }
+    __syncthreads();
+
+    // local reorder through LDS
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        if (rk[j] != 0xFFFFFFFFu) {
+            const uint32_t d = rk[j] >> 16;
+            const uint32_t lp = wcnt[wave][d] + (rk[j] & 0xFFFFu);
+            skey[lp] = k[j];
+            spos[lp] = p[j];
+            if (HAS_SEG) sseg[lp] = s[j];
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t idx = threadIdx.x; idx < tile_count; idx += RX_THREADS) {
+        const uint64_t kk = skey[idx];
+        const uint32_t ss = HAS_SEG ? sseg[idx] : 0u;
+        const uint32_t d = digit_of<SRC>(kk, ss, shift);
+        const uint32_t o = gbase[d] + idx;
+        key_out[o] = kk;
+        pos_out[o] = spos[idx];
+        if (HAS_SEG) seg_out[o] = ss;
+    }
+}
+
+template <int SRC, bool HAS_SEG>
+int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift)
+{
+    const uint64_t tiles = div_up(count, RX_TILE);
+    if (256 * tiles + 1 > ctx->tile_hist_cap) return KISS_HIP_E_INTERNAL;
+    const int dst = src ^ 1;
+    {
+        KTimer t(ctx, KISS_HIP_K_RADIX_HIST, count);
+        hipLaunchKernelGGL((k_radix_hist<SRC>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream, b.key[src],
+                           b.seg[src], count, shift, ctx->tile_hist, tiles);
+        KCHECK(hipGetLastError());
+    }
+    KTRY(kiss_scan_u32(ctx, ctx->tile_hist, ctx->tile_hist, 256 * tiles));
+    {
+        KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
+        hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
+                           b.key[src], b.seg[src], b.pos[src], b.key[dst], b.seg[dst], b.pos[dst], count, shift,
+                           ctx->tile_hist, tiles);
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}
+
+} // namespace
+
+int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx)
+{
+    int cur = 0;
+    if (count > 1) {
+        const bool has_seg = seg_bits > 0;
+        for (int shift = key_lo_bit & ~7; shift < 64; shift += 8) {
+            if (has_seg) KTRY((radix_pass<0, true>(ctx, b, cur, count, shift)));
+            else KTRY((radix_pass<0, false>(ctx, b, cur, count, shift)));
+            cur ^= 1;
+        }
+        for (int shift = 0; shift < seg_bits; shift += 8) {
+            KTRY((radix_pass<1, true>(ctx, b, cur, count, shift)));
+            cur ^= 1;
+        }
+    }
+    *result_idx = cur;
+    return KISS_HIP_OK;
+}

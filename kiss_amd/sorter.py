@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference facade for the hot path.
+
+Mirrors biovoltron::KISS1Sorter<uint32_t> / KISS2Sorter<uint32_t>
+(reference include/biovoltron/algo/sort/kiss1_sorter.hpp:8-50, kiss2_sorter.hpp:8-50):
+static `get_suffix_array_dna(S, k, num_threads)` returning an SA of n+1 entries, and
+`prepare_aligned_ref`.  `num_threads` is accepted and ignored: no result depends on it
+(the reference's KISS1 output is thread-count independent as well).
+
+Everything here calls the C ABI of libkiss_hip.so; there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+K_UNBOUNDED = 0xFFFFFFFF  # the CLI's `-k -1` (size_t max truncated to uint32_t, suffix_sort.hpp:35-37)
+
+
+def _check(status, where, ctx=None):
+    if status != _lib.KISS_HIP_OK:
+        detail = ""
+        if ctx is not None:
+            msg = ctypes.c_char_p()
+            code = _lib.load().kiss_hip_last_hip_error(ctx, ctypes.byref(msg))
+            if code:
+                detail = "hip error %d: %s" % (code, (msg.value or b"").decode())
+        raise _lib.KissHipError(status, where, detail)
+
+
+class Context:
+    """Device workspace for texts up to max_n bases on one GPU (kiss_hip_ctx)."""
+
+    def __init__(self, max_n, device=0, profiling=False):
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        _check(self._lib.kiss_hip_ctx_create(ctypes.byref(self._ctx), int(device), int(max_n)), "kiss_hip_ctx_create")
+        self.max_n = int(max_n)
+        self.device = int(device)
+        if profiling:
+            self.set_profiling(True)
+
+    def close(self):
+        if self._ctx:
+            self._lib.kiss_hip_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_profiling(self, on):
+        _check(self._lib.kiss_hip_ctx_set_profiling(self._ctx, 1 if on else 0), "kiss_hip_ctx_set_profiling")
+
+    def workspace_bytes(self):
+        v = ctypes.c_uint64()
+        _check(self._lib.kiss_hip_ctx_workspace_bytes(self._ctx, ctypes.byref(v)), "kiss_hip_ctx_workspace_bytes")
+        return v.value
+
+    def stats(self):
+        st = _lib.Stats()
+        _check(self._lib.kiss_hip_get_stats(self._ctx, ctypes.byref(st)), "kiss_hip_get_stats")
+        return st.as_dict()
+
+    def suffix_sort(self, S, k=256, algo=_lib.ALGO_PARALLEL_SORTING):
+        """S: uint8 numpy array (values 0..3) in host memory -> SA (uint32, n+1)."""
+        S = np.ascontiguousarray(S, dtype=np.uint8)
+        n = S.size
+        SA = np.empty(n + 1, dtype=np.uint32)
+        _check(self._lib.kiss_hip_ctx_suffix_sort_dna_u32(self._ctx, S.ctypes.data, n, int(k) & 0xFFFFFFFF, int(algo),
+                                                          SA.ctypes.data), "kiss_hip_ctx_suffix_sort_dna_u32", self._ctx)
+        return SA
+
+    def suffix_sort_dev(self, d_S_ptr, n, d_SA_ptr, k=256, algo=_lib.ALGO_PARALLEL_SORTING, stream=None):
+        """Device-resident form: raw device pointers (e.g. torch tensor .data_ptr())."""
+        _check(self._lib.kiss_hip_ctx_suffix_sort_dna_u32_dev(self._ctx, ctypes.c_void_p(d_S_ptr), int(n),
+                                                              int(k) & 0xFFFFFFFF, int(algo), ctypes.c_void_p(d_SA_ptr),
+                                                              ctypes.c_void_p(stream or 0)),
+               "kiss_hip_ctx_suffix_sort_dna_u32_dev", self._ctx)
+
+    def stage_outputs(self):
+        """(ascending LMS positions, k-ordered LMS positions, counts[12]) of the last sort."""
+        st = self.stats()
+        m = st["m"]
+        asc = np.empty(m, dtype=np.uint32)
+        srt = np.empty(m, dtype=np.uint32)
+        counts = np.zeros(12, dtype=np.uint64)
+        _check(self._lib.kiss_hip_ctx_get_stage_outputs(self._ctx, asc.ctypes.data, srt.ctypes.data,
+                                                        counts.ctypes.data), "kiss_hip_ctx_get_stage_outputs", self._ctx)
+        return asc, srt, counts
+
+
+class KISS1Sorter:
+    """PARALLEL_SORTING (kiss1_sorter.hpp:8-50)."""
+    algo = _lib.ALGO_PARALLEL_SORTING
+
+    @staticmethod
+    def prepare_aligned_ref(seq):
+        # reference: copy into a 64-byte aligned vector<uint8_t> (kiss1_sorter.hpp:46-49); numpy owns alignment here
+        return np.ascontiguousarray(np.asarray(seq, dtype=np.uint8))
+
+    @classmethod
+    def get_suffix_array_dna(cls, S, k=256, num_threads=None, device=0):
+        S = cls.prepare_aligned_ref(S)
+        SA = np.empty(S.size + 1, dtype=np.uint32)
+        lib = _lib.load()
+        _check(lib.kiss_hip_suffix_sort_dna_u32(S.ctypes.data, S.size, int(k) & 0xFFFFFFFF, cls.algo, SA.ctypes.data,
+                                                int(device)), "kiss_hip_suffix_sort_dna_u32")
+        return SA
+
+
+class KISS2Sorter(KISS1Sorter):
+    """PREFIX_DOUBLING (kiss2_sorter.hpp:8-50); defined for k >= n (exact suffix array) only."""
+    algo = _lib.ALGO_PREFIX_DOUBLING
