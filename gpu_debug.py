@@ -1,54 +1,44 @@
-"""First-contact GPU script: runs a few sizes and prints stage-by-stage diagnostics."""
-import sys, time, traceback
+"""GPU diagnostics: parity + per-kernel-class timing for selected cases."""
+import sys, time
 import numpy as np
 sys.path.insert(0, '.')
 import kiss_amd
 from tests import gen, oracle_binding
 orc = oracle_binding.load()
-ctx = kiss_amd.Context(max_n=6_000_000)
+MAXN = int(sys.argv[1]) if len(sys.argv) > 1 else 6_000_000
+ctx = kiss_amd.Context(max_n=MAXN)
 print("workspace MB", ctx.workspace_bytes() / 1e6, flush=True)
-def run(name, S, k):
+def run(name, S, k, prof=False, check=True, reps=1):
     S = np.ascontiguousarray(S, np.uint8); n = S.size
-    t = time.time()
-    try:
-        sa = ctx.suffix_sort(S, k)
-    except Exception as e:
-        print(name, n, k, "EXC", e, flush=True); return False
-    dt = time.time() - t
-    ref, lref = orc.suffix_sort(S, k, stages=True)
+    ctx.set_profiling(prof)
+    for _ in range(reps):
+        t = time.time(); sa = ctx.suffix_sort(S, k); dt = time.time() - t
     st = ctx.stats()
-    ok = True
-    if n:
-        asc, srt, counts = ctx.stage_outputs()
-        lr, hist = orc.get_lms(S)
-        a_ok = asc.size == lr.size - 1 and np.array_equal(asc, lr[:-1])
-        c_ok = np.array_equal(counts[0:4], hist[4,:4]) and np.array_equal(counts[8:12], hist[2,:4])
-        s_ok = srt.size == lref.size - 1 and np.array_equal(srt, lref[1:])
-        f_ok = np.array_equal(sa, ref)
-        ok = a_ok and c_ok and s_ok and f_ok
-        print("%-22s n=%8d k=%10d lms_asc=%s counts=%s lms_sorted=%s SA=%s  m=%d rounds=%d passes=%d near=%d  %.1f ms (dev %.2f: pack %.2f cls %.2f sort %.2f place %.2f ind %.2f)" % (
-            name, n, k, a_ok, c_ok, s_ok, f_ok, st['m'], st['lms_rounds'], st['induce_passes'], st['near_end'], dt*1e3,
-            st['ms_total'], st['ms_pack'], st['ms_classify'], st['ms_lms_sort'], st['ms_place'], st['ms_induce']), flush=True)
-        if not a_ok:
-            print("   asc size", asc.size, lr.size - 1, "first diff", (np.nonzero(asc[:min(asc.size, lr.size-1)] != lr[:min(asc.size, lr.size-1)])[0][:5]), flush=True)
-            print("   counts", counts, hist[4,:4], hist[2,:4])
-        elif not s_ok:
-            bad = np.nonzero(srt != lref[1:])[0]; print("   sorted lms bad", bad.size, bad[:5], srt[bad[:5]], lref[1:][bad[:5]], flush=True)
-        elif not f_ok:
-            bad = np.nonzero(sa != ref)[0]; print("   SA bad", bad.size, bad[:8], sa[bad[:8]], ref[bad[:8]], flush=True)
-    else:
-        ok = np.array_equal(sa, ref); print(name, n, k, "SA", ok)
+    ok = None
+    if check:
+        ref = orc.suffix_sort(S, k); ok = bool(np.array_equal(sa, ref))
+    print("%-14s n=%9d k=%10d SA=%s m=%d rounds=%d itemrounds=%d passes=%d near=%d wall %.1f ms dev %.2f: pack %.2f cls %.2f sort %.2f place %.2f ind %.2f  -> %.1f Mbases/s" % (
+        name, n, k, ok, st['m'], st['lms_rounds'], st['sort_item_rounds'], st['induce_passes'], st['near_end'], dt*1e3,
+        st['ms_total'], st['ms_pack'], st['ms_classify'], st['ms_lms_sort'], st['ms_place'], st['ms_induce'], n / max(st['ms_total'],1e-9) / 1e3), flush=True)
+    if prof:
+        for kname, v in st['kernels'].items():
+            if v['launches']:
+                print("      %-15s ms %9.3f launches %6d items %12d  avg %.1f us" % (kname, v['ms'], v['launches'], v['items'], 1e3*v['ms']/v['launches']), flush=True)
     return ok
-allok = True
-for n in [0, 1, 2, 5, 33, 200, 1000, 5000, 100_003, 1_000_000]:
-    for k in [256, 32, 0xFFFFFFFF]:
-        allok &= run("iid", gen.iid(n, 1000 + n), k)
-for per in [1, 2, 3, 7, 37, 400]:
-    for k in [256, 0xFFFFFFFF]:
-        allok &= run("periodic%d" % per, gen.periodic(20000, per, 7 + per, 6), k)
-allok &= run("allA", np.zeros(3000, np.uint8), 256)
-allok &= run("allT", np.full(3000, 3, np.uint8), 256)
-allok &= run("genome2M", gen.genome_like(2_000_000, 11), 256)
-allok &= run("genome2M", gen.genome_like(2_000_000, 11), 32)
-allok &= run("iid5M", gen.iid(5_000_000, 5), 256)
-print("ALL OK" if allok else "FAILURES", flush=True)
+run("warm", gen.iid(100000, 1), 256)
+run("periodic1", gen.periodic(20000, 1, 8, 6), 256, prof=True)
+run("periodic1", gen.periodic(20000, 1, 8, 6), 256, prof=False)
+run("periodic7", gen.periodic(20000, 7, 14, 6), 256, prof=True)
+run("periodic400", gen.periodic(20000, 400, 407, 6), 256, prof=True)
+run("periodic400", gen.periodic(20000, 400, 407, 6), 256, prof=False)
+G = gen.genome_like(2_000_000, 11)
+run("genome2M", G, 256, prof=True)
+run("genome2M", G, 256, prof=False)
+if MAXN >= 50_000_000:
+    S = gen.iid(50_000_000, 5)
+    run("iid50M", S, 256, reps=2)
+    run("iid50M", S, 256, prof=True, check=False)
+    G = gen.genome_like(50_000_000, 1)
+    run("genome50M", G, 256, reps=2)
+    run("genome50M", G, 256, prof=True, check=False)
+    run("genome50M", G, 0xFFFFFFFF, check=True)
