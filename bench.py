@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py -- bases/sec of k-ordered suffix sorting on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (pack -> get_lms -> k-ordered LMS sort -> induction) over one
+synthetic chm13-sized text (n = 3 117 292 070, k = 256) that is already resident in HBM when the
+timed region starts; the SA stays in HBM.  One process per GPU.  For N > 1 each rank sorts its own
+text of the same size (independent objects, no data-path collective): weak scaling.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CHM13_N = 3_117_292_070  # reference README.md:101
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+# algorithmic bytes per item of each kernel class (DESIGN.md section "Kernels"): bytes that must move
+# through HBM for one item even with perfect caching
+ALGO_BYTES = {
+    "radix_scatter": 24.0,   # read key64+pos32, write key64+pos32 (a seg32 adds 8 in refinement rounds; not counted)
+    "radix_hist": 8.0,       # read key64
+    "induce_scatter": 16.0,  # read pos32+ctx32, write pos32+ctx32 of the induced item
+    "induce_count": 4.0,     # read ctx32
+    "classify": 0.25,        # 2-bit text, per base per launch
+    "pack": 1.25,            # read 1 byte, write 2 bits
+    "scan": 8.0,             # read + write u32
+    "place": 12.0,           # read pos32, write pos32 + ctx32 (+ one text gather)
+    "keygather": 12.0,       # read pos32, write key64 (+ one text gather)
+    "flag_compact": 28.0,
+    "induce_small": 16.0,
+}
+
+
+def gen_text_device(n, seed, device):
+    """Genome-like synthetic text on the GPU (torch ops only; deterministic for a given seed).
+    Same recipe as tests/gen.py::genome_like."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    S = torch.randint(0, 4, (n,), dtype=torch.uint8, device=device, generator=g)
+    if n < 1_000_000:
+        return S
+    cpu = np.random.default_rng(seed)
+
+    def mutate(seg, rate):
+        if rate <= 0:
+            return seg
+        mask = torch.rand(seg.shape, device=device, generator=g) < rate
+        rnd = torch.randint(0, 4, seg.shape, dtype=torch.uint8, device=device, generator=g)
+        return torch.where(mask, rnd, seg)
+
+    # interspersed repeats: 10 families x 300 bases, 10 % of the text, 10 % divergence
+    fams = torch.randint(0, 4, (10, 300), dtype=torch.uint8, device=device, generator=g)
+    n_ins = int(0.10 * n / 300)
+    chunk = 200_000
+    ar = torch.arange(300, device=device, dtype=torch.int64)
+    for b in range(0, n_ins, chunk):
+        c = min(chunk, n_ins - b)
+        pos = torch.randint(0, n - 300, (c,), device=device, generator=g, dtype=torch.int64)
+        fam = torch.randint(0, 10, (c,), device=device, generator=g, dtype=torch.int64)
+        vals = mutate(fams[fam], 0.10)
+        idx = (pos[:, None] + ar[None, :]).reshape(-1)
+        S[idx] = vals.reshape(-1)
+        del idx, vals
+    # segmental duplications: 5 %, log-uniform 1e3..1e5, half exact
+    budget = int(0.05 * n)
+    while budget > 0:
+        L = int(np.exp(cpu.uniform(np.log(1e3), np.log(1e5))))
+        src = int(cpu.integers(0, n - L))
+        dst = int(cpu.integers(0, n - L))
+        seg = S[src:src + L].clone()
+        S[dst:dst + L] = seg if cpu.random() < 0.5 else mutate(seg, 0.01)
+        budget -= L
+    # tandem arrays: 3 %
+    budget = int(0.03 * n)
+    units = [1, 2, 3, 4, 5, 6, 12, 171]
+    while budget > 0:
+        u = units[int(cpu.integers(0, len(units)))]
+        L = int(min(1_000_000, max(200, 200 * (1.0 / max(1e-6, cpu.random())) ** 0.7)))
+        p = int(cpu.integers(0, n - L))
+        unit = torch.randint(0, 4, (u,), dtype=torch.uint8, device=device, generator=g)
+        S[p:p + L] = mutate(unit.repeat(L // u + 1)[:L], 0.005)
+        budget -= L
+    tel = torch.tensor([3, 3, 0, 2, 2, 2], dtype=torch.uint8, device=device).repeat(500)
+    for c in range(24):
+        e = (c + 1) * (n // 24)
+        S[e - tel.numel():e] = tel
+    return S
+
+
+def cpu_baseline(S_host_sample, k):
+    """Times the CPU oracle (a port: plain C restatement of the reference algorithm, OpenMP only in the
+    per-bucket LMS sort) on a bounded sample.  Reported baseline, not the optimisation target."""
+    from tests import oracle_binding
+    orc = oracle_binding.load()
+    t0 = time.time()
+    orc.suffix_sort(S_host_sample, k)
+    dt = time.time() - t0
+    return {"value": S_host_sample.size / dt, "unit": "bases/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "first %d bases of the same synthetic text, k=%d, %.1f s" % (S_host_sample.size, k, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=CHM13_N, help="text length (default: chm13v2.0 size)")
+    ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import kiss_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    n, k = args.n, args.k
+    seed = args.seed + 1000 * rank
+    if args.iid:
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        S = torch.randint(0, 4, (n,), dtype=torch.uint8, device=device, generator=g)
+    else:
+        S = gen_text_device(n, seed, device)
+    SA = torch.empty(n + 1, dtype=torch.int32, device=device)  # u32 payload; torch has no uint32 arithmetic needs
+    torch.cuda.synchronize()
+
+    ctx = kiss_amd.Context(max_n=n, device=local_rank, profiling=not args.no_profile)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    agg = {}
+    stage = {"pack": 0.0, "classify": 0.0, "lms_sort": 0.0, "place": 0.0, "induce": 0.0, "total": 0.0}
+    last_stats = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        st = ctx.stats()
+        last_stats = st
+        for name, v in st["kernels"].items():
+            a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "items": 0})
+            a["ms"] += v["ms"]
+            a["launches"] += v["launches"]
+            a["items"] += v["items"]
+        for s in stage:
+            stage[s] += st["ms_" + s]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_bases = float(n) * args.steps * world
+        value = total_bases / elapsed
+        out = {
+            "metric": "bases/sec suffix_sort (chm13v2.0-size synthetic, k=%d)" % k,
+            "value": value,
+            "unit": "bases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "suffix_sort %s n=%d k=%d (stand-in for chm13v2.0.fa, BASELINE.json configs[1]); "
+                            "PARALLEL_SORTING; text resident in HBM, SA left in HBM"
+                            % ("i.i.d." if args.iid else "genome-like synthetic", n, k),
+                "n": n, "k": k, "seed": args.seed,
+                "parallelism": "1 text per GPU" if world > 1 else "single GPU",
+                "lms": last_stats["m"], "lms_rounds": last_stats["lms_rounds"],
+                "induce_passes": last_stats["induce_passes"],
+                "stage_ms_per_step": {s: v / args.steps for s, v in stage.items()},
+            },
+        }
+        # roofline of the dominant kernel class (live HIP-event timing inside the library)
+        roof = None
+        if agg and not args.no_profile:
+            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            name, a = dom
+            if a["launches"] and a["ms"] > 0:
+                bytes_per_launch = ALGO_BYTES.get(name, 0.0) * a["items"] / a["launches"]
+                avg_s = 1e-3 * a["ms"] / a["launches"]
+                achieved = bytes_per_launch / avg_s / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / args.steps,
+                        "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
+                        "kernel_ms_per_step": {kn: kv["ms"] / args.steps for kn, kv in agg.items() if kv["launches"]}}
+        out["roofline"] = roof
+        # whole-path algorithmic bytes: 0.25 n + 20 m + 16 (n+1) + 2 n
+        m = last_stats["m"]
+        path_bytes = 0.25 * n + 20.0 * m + 16.0 * (n + 1) + 2.0 * n
+        dev_s = 1e-3 * stage["total"] / args.steps
+        out["path_roofline"] = {"algorithmic_bytes": path_bytes, "device_ms": 1e3 * dev_s,
+                                "achieved_GBps": path_bytes / dev_s / 1e9, "frac": path_bytes / dev_s / 1e9 / HBM_PEAK_GBS}
+        if args.cpu_sample > 0 and world == 1:
+            ns = min(n, args.cpu_sample)
+            sample = S[:ns].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample, k)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
