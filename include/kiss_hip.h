@@ -61,6 +61,7 @@ typedef struct kiss_hip_stats {
     uint32_t induce_passes;  /* stable-partition passes executed by the two sweeps */
     uint64_t near_end;       /* LMS suffixes ranked by the near-end rule */
     uint64_t sort_item_rounds; /* sum over rounds of active LMS items */
+    uint64_t big_item_rounds;  /* of those, items that went through the radix path in rounds >= 1 */
     float ms_total;          /* device time of the whole call (HIP events) */
     float ms_pack;           /* 2-bit packing */
     float ms_classify;       /* get_lms: classification + LMS extraction */
@@ -88,7 +89,8 @@ enum {
     KISS_HIP_K_INDUCE_SMALL = 10,
     KISS_HIP_K_FM_QUERY = 11,
     KISS_HIP_K_FM_BUILD = 12,
-    KISS_HIP_K_NCLASSES = 13
+    KISS_HIP_K_SEGRANK = 13,
+    KISS_HIP_K_NCLASSES = 14
 };
 
 int kiss_hip_version(void);

@@ -17,7 +17,7 @@ MAX_N = 4294967276
 
 KERNEL_CLASSES = [
     "pack", "classify", "radix_hist", "radix_scatter", "scan", "keygather", "flag_compact",
-    "place", "induce_count", "induce_scatter", "induce_small", "fm_query", "fm_build",
+    "place", "induce_count", "induce_scatter", "induce_small", "fm_query", "fm_build", "segrank",
 ]
 
 
@@ -25,7 +25,7 @@ class Stats(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_uint64), ("m", ctypes.c_uint64), ("k", ctypes.c_uint32), ("depth", ctypes.c_uint32),
         ("lms_rounds", ctypes.c_uint32), ("induce_passes", ctypes.c_uint32), ("near_end", ctypes.c_uint64),
-        ("sort_item_rounds", ctypes.c_uint64),
+        ("sort_item_rounds", ctypes.c_uint64), ("big_item_rounds", ctypes.c_uint64),
         ("ms_total", ctypes.c_float), ("ms_pack", ctypes.c_float), ("ms_classify", ctypes.c_float),
         ("ms_lms_sort", ctypes.c_float), ("ms_place", ctypes.c_float), ("ms_induce", ctypes.c_float),
         ("ms_kernel", ctypes.c_float * 16), ("launches_kernel", ctypes.c_uint64 * 16),

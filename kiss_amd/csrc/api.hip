@@ -54,13 +54,28 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
     return KISS_HIP_OK;
 }
 
+void free_lms_side(kiss_hip_ctx *ctx)
+{
+    void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
+                     (void **)&ctx->posB, (void **)&ctx->segA, (void **)&ctx->segB, (void **)&ctx->slotA,
+                     (void **)&ctx->slotB, (void **)&ctx->segstartA, (void **)&ctx->segstartB, (void **)&ctx->bkeyA,
+                     (void **)&ctx->bkeyB, (void **)&ctx->bposA, (void **)&ctx->bposB, (void **)&ctx->bsegA,
+                     (void **)&ctx->bsegB, (void **)&ctx->bslot, (void **)&ctx->flags, (void **)&ctx->lms_sorted_far,
+                     (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp};
+    for (void **p : ptrs)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    ctx->ws_bytes -= ctx->lms_bytes;
+    ctx->lms_bytes = 0;
+}
+
 void free_all(kiss_hip_ctx *ctx)
 {
-    void *ptrs[] = {ctx->pk,   ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->lms_pos,  ctx->keyA,
-                    ctx->keyB, ctx->posA,    ctx->posB,     ctx->segA,     ctx->segB,     ctx->slotA,
-                    ctx->slotB, ctx->flags,  ctx->lms_sorted_far, ctx->lmsP, ctx->lmsC,   ctx->tile_hist,
-                    ctx->scan_tmp, ctx->CTX, ctx->ind_counts, ctx->d_small, ctx->near_idx, ctx->near_fin,
-                    ctx->near_pos};
+    free_lms_side(ctx);
+    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
+                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -139,6 +154,51 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
 
 } // namespace
 
+int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
+{
+    free_lms_side(ctx);
+    const uint64_t before = ctx->ws_bytes;
+    ctx->m_cap = m_cap;
+    const uint64_t radix_tiles = m_cap / 4096 + 2;
+    ctx->tile_hist_cap = 256 * radix_tiles + 256 * (radix_tiles / 64 + 2) + 8;
+    uint64_t biggest_scan = m_cap;
+    if (ctx->tile_hist_cap > biggest_scan) biggest_scan = ctx->tile_hist_cap;
+    if (ctx->ind_tiles_cap > biggest_scan) biggest_scan = ctx->ind_tiles_cap;
+    if (ctx->n_tiles_cap > biggest_scan) biggest_scan = ctx->n_tiles_cap;
+    ctx->scan_tmp_cap = biggest_scan / 4096 + 16;
+    int rc = KISS_HIP_OK;
+    do {
+#define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
+        ALLOC(lms_pos, m_cap);
+        ALLOC(keyA, m_cap);
+        ALLOC(keyB, m_cap);
+        ALLOC(posA, m_cap);
+        ALLOC(posB, m_cap);
+        ALLOC(segA, m_cap);
+        ALLOC(segB, m_cap);
+        ALLOC(slotA, m_cap);
+        ALLOC(slotB, m_cap);
+        ALLOC(segstartA, m_cap + 2);
+        ALLOC(segstartB, m_cap + 2);
+        ALLOC(bkeyA, m_cap);
+        ALLOC(bkeyB, m_cap);
+        ALLOC(bposA, m_cap);
+        ALLOC(bposB, m_cap);
+        ALLOC(bsegA, m_cap);
+        ALLOC(bsegB, m_cap);
+        ALLOC(bslot, m_cap);
+        ALLOC(flags, 2 * m_cap);
+        ALLOC(lms_sorted_far, m_cap);
+        ALLOC(lmsP, m_cap);
+        ALLOC(lmsC, m_cap);
+        ALLOC(tile_hist, ctx->tile_hist_cap);
+        ALLOC(scan_tmp, ctx->scan_tmp_cap);
+#undef ALLOC
+    } while (0);
+    ctx->lms_bytes = ctx->ws_bytes - before;
+    return rc;
+}
+
 extern "C" {
 
 int kiss_hip_version(void) { return KISS_HIP_VERSION; }
@@ -189,36 +249,13 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
         const uint64_t words = max_n / 32 + 8;
         ctx->pk_words = words;
         ctx->n_tiles_cap = words / 256 + 2;
-        ctx->m_cap = max_n / 2 + 2;
-        const uint64_t radix_tiles = ctx->m_cap / 4096 + 2;
-        ctx->tile_hist_cap = 256 * radix_tiles + 8;
         ctx->ind_tiles_cap = 4 * ((max_n + 1) / 2048 + 2) + 2;
-        uint64_t biggest_scan = ctx->m_cap;
-        if (ctx->tile_hist_cap > biggest_scan) biggest_scan = ctx->tile_hist_cap;
-        if (ctx->ind_tiles_cap > biggest_scan) biggest_scan = ctx->ind_tiles_cap;
-        if (ctx->n_tiles_cap > biggest_scan) biggest_scan = ctx->n_tiles_cap;
-        ctx->scan_tmp_cap = biggest_scan / 4096 + 16;
         ctx->near_cap = 65536;
 #define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
         ALLOC(pk, words);
         ALLOC(tile_gp, ctx->n_tiles_cap);
         ALLOC(tile_cnt, ctx->n_tiles_cap);
         ALLOC(d_counts, 16);
-        ALLOC(lms_pos, ctx->m_cap);
-        ALLOC(keyA, ctx->m_cap);
-        ALLOC(keyB, ctx->m_cap);
-        ALLOC(posA, ctx->m_cap);
-        ALLOC(posB, ctx->m_cap);
-        ALLOC(segA, ctx->m_cap);
-        ALLOC(segB, ctx->m_cap);
-        ALLOC(slotA, ctx->m_cap);
-        ALLOC(slotB, ctx->m_cap);
-        ALLOC(flags, 2 * ctx->m_cap);
-        ALLOC(lms_sorted_far, ctx->m_cap);
-        ALLOC(lmsP, ctx->m_cap);
-        ALLOC(lmsC, ctx->m_cap);
-        ALLOC(tile_hist, ctx->tile_hist_cap);
-        ALLOC(scan_tmp, ctx->scan_tmp_cap);
         ALLOC(CTX, max_n + 2);
         ALLOC(ind_counts, ctx->ind_tiles_cap);
         ALLOC(d_small, 64);
@@ -226,6 +263,10 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
         ALLOC(near_fin, ctx->near_cap);
         ALLOC(near_pos, ctx->near_cap);
 #undef ALLOC
+        // LMS-sized arrays: DNA has ~0.29-0.30 n LMS suffixes; inputs with more (up to n/2) re-reserve on demand
+        uint64_t m0 = (uint64_t)(0.32 * (double)max_n) + 4096;
+        if (m0 > max_n / 2 + 2) m0 = max_n / 2 + 2;
+        if ((rc = kiss_lms_reserve(ctx, m0))) break;
         void *hp = nullptr;
         if (hipHostMalloc(&hp, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
             rc = KISS_HIP_E_NOMEM;

@@ -342,7 +342,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
     uint64_t m = (uint64_t)ctx->h_pinned[8] + ctx->h_pinned[9] + ctx->h_pinned[10] + ctx->h_pinned[11];
     ctx->m = m;
     ctx->m_far = none_far ? 0 : ctx->h_pinned[12];
-    if (m > ctx->m_cap) return KISS_HIP_E_INTERNAL;
+    if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024)); // more LMS suffixes than DNA-typical
     if (m > 0) {
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
         hipLaunchKernelGGL(k_classify<true>, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,

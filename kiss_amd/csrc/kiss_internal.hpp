@@ -35,6 +35,7 @@ struct kiss_hip_ctx {
     uint64_t max_n = 0;
     uint64_t m_cap = 0;            // capacity of LMS arrays
     uint64_t ws_bytes = 0;
+    uint64_t lms_bytes = 0;
 
     // text
     uint64_t *pk = nullptr;        // 2-bit packed text, base i at bits [63-2(i%32), 62-2(i%32)] of word i/32
@@ -50,6 +51,9 @@ struct kiss_hip_ctx {
     uint32_t *posA = nullptr, *posB = nullptr;
     uint32_t *segA = nullptr, *segB = nullptr;
     uint32_t *slotA = nullptr, *slotB = nullptr;
+    uint32_t *segstartA = nullptr, *segstartB = nullptr; // first active index of every tied segment (+1 end entry)
+    uint64_t *bkeyA = nullptr, *bkeyB = nullptr;         // radix path of big segments in rounds >= 1
+    uint32_t *bposA = nullptr, *bposB = nullptr, *bsegA = nullptr, *bsegB = nullptr, *bslot = nullptr;
     uint64_t *flags = nullptr;     // per active item: (survivor << 32) | surviving-head, then its exclusive scan
     uint32_t *lms_sorted_far = nullptr; // far LMS suffixes in k-order
     uint32_t *lmsP = nullptr;      // all LMS suffixes in k-order (sentinel excluded)
@@ -91,6 +95,8 @@ void ktimer_collect(kiss_hip_ctx *ctx);
 static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 // ---- stages (host drivers) -------------------------------------------------------
+// (re)allocates every LMS-sized array for at least m_cap suffixes
+int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
 // classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
 int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*/);

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
         }
     }
     __syncthreads();
-    tile_hist[(uint64_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
+    tile_hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x]; // tile-major: one coalesced 1 KiB row
+    (void)tiles;
 }
 
 template <int SRC, bool HAS_SEG>
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__
         __syncthreads();
         uint32_t start = inc - tot;
         for (int w = 0; w < wave; w++) start += wsum[w];
-        gbase[d] = tile_off[(uint64_t)d * tiles + blockIdx.x] - start;
+        gbase[d] = tile_off[(uint64_t)blockIdx.x * 256 + d] - start;
+        (void)tiles;
         uint32_t run = start;
 #pragma unroll
         for (int w = 0; w < RX_WAVES; w++) {
@@ -157,11 +159,80 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__
     }
 }
 
+// ---- digit-major exclusive scan of the tile-major histogram matrix hist[tile][256] ------------------
+// offset(tile, d) = sum over digits d' < d of total[d'] + sum over tiles t' < tile of hist[t'][d].
+// k_col_sum: per chunk of RX_CHUNK tiles, column sums -> digit-major chunk matrix csum[d][chunk];
+// generic exclusive scan over csum (digit-major linear order is exactly the order wanted);
+// k_col_apply: per chunk, running column prefix written back over hist.  Rows are coalesced 1 KiB.
+constexpr int RX_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void k_col_sum(const uint32_t *__restrict__ hist, uint64_t tiles, uint64_t chunks,
+                                                 uint32_t *__restrict__ csum)
+{
+    const uint64_t t0 = (uint64_t)blockIdx.x * RX_CHUNK;
+    const uint64_t t1 = t0 + RX_CHUNK < tiles ? t0 + RX_CHUNK : tiles;
+    uint32_t s = 0;
+    uint64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = hist[(t + u) * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; t < t1; t++) s += hist[t * 256 + threadIdx.x];
+    csum[(uint64_t)threadIdx.x * chunks + blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_col_apply(uint32_t *hist, uint64_t tiles, uint64_t chunks,
+                                                   const uint32_t *__restrict__ coff)
+{
+    const uint64_t t0 = (uint64_t)blockIdx.x * RX_CHUNK;
+    const uint64_t t1 = t0 + RX_CHUNK < tiles ? t0 + RX_CHUNK : tiles;
+    uint32_t run = coff[(uint64_t)threadIdx.x * chunks + blockIdx.x];
+    uint64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = hist[(t + u) * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            hist[(t + u) * 256 + threadIdx.x] = run;
+            run += v[u];
+        }
+    }
+    for (; t < t1; t++) {
+        uint32_t v = hist[t * 256 + threadIdx.x];
+        hist[t * 256 + threadIdx.x] = run;
+        run += v;
+    }
+}
+
+int radix_offsets(kiss_hip_ctx *ctx, uint64_t tiles)
+{
+    const uint64_t chunks = div_up(tiles, RX_CHUNK);
+    uint32_t *csum = ctx->tile_hist + 256 * tiles; // room reserved behind the matrix
+    if (256 * tiles + 256 * chunks > ctx->tile_hist_cap) return KISS_HIP_E_INTERNAL;
+    {
+        KTimer t(ctx, KISS_HIP_K_SCAN, 256 * tiles);
+        hipLaunchKernelGGL(k_col_sum, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, ctx->tile_hist, tiles, chunks,
+                           csum);
+        KCHECK(hipGetLastError());
+    }
+    KTRY(kiss_scan_u32(ctx, csum, csum, 256 * chunks));
+    {
+        KTimer t(ctx, KISS_HIP_K_SCAN, 256 * tiles);
+        hipLaunchKernelGGL(k_col_apply, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, ctx->tile_hist, tiles,
+                           chunks, csum);
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}
+
 template <int SRC, bool HAS_SEG>
 int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift)
 {
     const uint64_t tiles = div_up(count, RX_TILE);
-    if (256 * tiles + 1 > ctx->tile_hist_cap) return KISS_HIP_E_INTERNAL;
     const int dst = src ^ 1;
     {
         KTimer t(ctx, KISS_HIP_K_RADIX_HIST, count);
@@ -169,7 +240,7 @@ int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shi
                            b.seg[src], count, shift, ctx->tile_hist, tiles);
         KCHECK(hipGetLastError());
     }
-    KTRY(kiss_scan_u32(ctx, ctx->tile_hist, ctx->tile_hist, 256 * tiles));
+    KTRY(radix_offsets(ctx, tiles));
     {
         KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
         hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,

@@ -1,13 +1,18 @@
 // scan.hip -- device-wide exclusive prefix sums (u32 / u64), three launches:
 // per-block reduce -> single-workgroup scan of block sums -> per-block scan + add.
 // No inter-workgroup spinning: every launch is a plain data-parallel kernel.
+//
+// A block covers 4096 elements as 4 rows of 1024; a thread owns 4 consecutive elements of every row,
+// so every load/store instruction is a fully coalesced 16 B (u32) or 32 B (u64) per lane.
 #include "kiss_internal.hpp"
 
 namespace {
 
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ELEMS = 16;
-constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ELEMS; // 4096 elements per workgroup
+constexpr int SCAN_ROWS = 4;
+constexpr int SCAN_VEC = 4;
+constexpr int SCAN_ROW_ELEMS = SCAN_THREADS * SCAN_VEC;   // 1024
+constexpr int SCAN_BLOCK = SCAN_ROWS * SCAN_ROW_ELEMS;    // 4096 elements per workgroup
 
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v)
@@ -20,46 +25,64 @@ __device__ __forceinline__ T wave_inclusive_scan(T v)
     return v;
 }
 
-// exclusive scan of one value per thread across a workgroup of NT threads; returns exclusive prefix,
-// *total receives the workgroup total.  lds must hold NT/64 + 1 entries.
-template <typename T, int NT>
-__device__ __forceinline__ T block_exclusive_scan(T v, T *lds, T *total)
+template <typename T>
+__device__ __forceinline__ void load_row(const T *__restrict__ in, uint64_t base, uint64_t count, T v[SCAN_VEC])
 {
-    const int wave = threadIdx.x >> 6;
-    T inc = wave_inclusive_scan<T>(v);
-    if (lane_id() == 63) lds[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        T acc = 0;
-        for (int w = 0; w < NT / 64; w++) {
-            T t = lds[w];
-            lds[w] = acc;
-            acc += t;
+    if (base + SCAN_VEC <= count && ((reinterpret_cast<uintptr_t>(in + base) & (sizeof(T) * SCAN_VEC - 1)) == 0)) {
+        if constexpr (sizeof(T) == 4) {
+            uint4 q = *reinterpret_cast<const uint4 *>(in + base);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(in + base);
+            ulonglong2 a = p[0], b = p[1];
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
         }
-        lds[NT / 64] = acc;
+    } else {
+#pragma unroll
+        for (int e = 0; e < SCAN_VEC; e++) v[e] = (base + e < count) ? in[base + e] : (T)0;
     }
-    __syncthreads();
-    T res = inc - v + lds[wave];
-    *total = lds[NT / 64];
-    __syncthreads();
-    return res;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_row(T *__restrict__ out, uint64_t base, uint64_t count, const T v[SCAN_VEC])
+{
+    if (base + SCAN_VEC <= count && ((reinterpret_cast<uintptr_t>(out + base) & (sizeof(T) * SCAN_VEC - 1)) == 0)) {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<uint4 *>(out + base) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+            ulonglong2 *p = reinterpret_cast<ulonglong2 *>(out + base);
+            p[0] = make_ulonglong2(v[0], v[1]);
+            p[1] = make_ulonglong2(v[2], v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < SCAN_VEC; e++)
+            if (base + e < count) out[base + e] = v[e];
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const T *__restrict__ in, uint64_t count,
                                                              T *__restrict__ blocksums)
 {
-    __shared__ T lds[SCAN_THREADS / 64 + 1];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ELEMS;
+    __shared__ T lds[SCAN_THREADS / 64];
+    const uint64_t bbase = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_VEC;
     T s = 0;
 #pragma unroll
-    for (int e = 0; e < SCAN_ELEMS; e++) {
-        uint64_t i = base + e;
-        if (i < count) s += in[i];
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        T v[SCAN_VEC];
+        load_row<T>(in, bbase + (uint64_t)r * SCAN_ROW_ELEMS, count, v);
+        s += v[0] + v[1] + v[2] + v[3];
     }
-    T total;
-    (void)block_exclusive_scan<T, SCAN_THREADS>(s, lds, &total);
-    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane_id() == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; w++) t += lds[w];
+        blocksums[blockIdx.x] = t;
+    }
 }
 
 template <typename T>
@@ -71,8 +94,20 @@ __global__ __launch_bounds__(1024) void k_scan_single(T *__restrict__ data, uint
     const uint64_t end = beg + chunk < count ? beg + chunk : count;
     T s = 0;
     for (uint64_t i = beg; i < end; i++) s += data[i];
-    T total;
-    T run = block_exclusive_scan<T, 1024>(s, lds, &total);
+    const int wave = threadIdx.x >> 6;
+    T inc = wave_inclusive_scan<T>(s);
+    if (lane_id() == 63) lds[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T acc = 0;
+        for (int w = 0; w < 1024 / 64; w++) {
+            T t = lds[w];
+            lds[w] = acc;
+            acc += t;
+        }
+    }
+    __syncthreads();
+    T run = inc - s + lds[wave];
     for (uint64_t i = beg; i < end; i++) {
         T t = data[i];
         data[i] = run;
@@ -84,23 +119,39 @@ template <typename T>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T *in, T *out, uint64_t count,
                                                             const T *__restrict__ blocksums)
 {
-    __shared__ T lds[SCAN_THREADS / 64 + 1];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ELEMS;
-    T v[SCAN_ELEMS];
-    T s = 0;
+    __shared__ T wsum[SCAN_ROWS][SCAN_THREADS / 64];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t bbase = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_VEC;
+    T v[SCAN_ROWS][SCAN_VEC];
+    T c[SCAN_ROWS], inc[SCAN_ROWS];
 #pragma unroll
-    for (int e = 0; e < SCAN_ELEMS; e++) {
-        uint64_t i = base + e;
-        v[e] = (i < count) ? in[i] : (T)0;
-        s += v[e];
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        load_row<T>(in, bbase + (uint64_t)r * SCAN_ROW_ELEMS, count, v[r]);
+        c[r] = v[r][0] + v[r][1] + v[r][2] + v[r][3];
     }
-    T total;
-    T run = block_exclusive_scan<T, SCAN_THREADS>(s, lds, &total) + blocksums[blockIdx.x];
 #pragma unroll
-    for (int e = 0; e < SCAN_ELEMS; e++) {
-        uint64_t i = base + e;
-        if (i < count) out[i] = run;
-        run += v[e];
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        inc[r] = wave_inclusive_scan<T>(c[r]);
+        if (lane_id() == 63) wsum[r][wave] = inc[r];
+    }
+    __syncthreads();
+    T run = blocksums[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < SCAN_ROWS; r++) {
+        T pre = run;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            T t = wsum[r][w];
+            if (w < wave) pre += t;
+            run += t;
+        }
+        pre += inc[r] - c[r];
+        T o[SCAN_VEC];
+        o[0] = pre;
+        o[1] = o[0] + v[r][0];
+        o[2] = o[1] + v[r][1];
+        o[3] = o[2] + v[r][2];
+        store_row<T>(out, bbase + (uint64_t)r * SCAN_ROW_ELEMS, count, o);
     }
 }
 
