@@ -60,11 +60,13 @@ def gen_text_device(n, seed, device):
     # interspersed repeats: 10 families x 300 bases, 10 % of the text, 10 % divergence
     fams = torch.randint(0, 4, (10, 300), dtype=torch.uint8, device=device, generator=g)
     n_ins = int(0.10 * n / 300)
+    stratum = n // n_ins  # one insertion per stratum of ~3000 bases: no overlapping writes -> deterministic text
     chunk = 200_000
     ar = torch.arange(300, device=device, dtype=torch.int64)
     for b in range(0, n_ins, chunk):
         c = min(chunk, n_ins - b)
-        pos = torch.randint(0, n - 300, (c,), device=device, generator=g, dtype=torch.int64)
+        base = (torch.arange(b, b + c, device=device, dtype=torch.int64)) * stratum
+        pos = base + torch.randint(0, stratum - 300, (c,), device=device, generator=g, dtype=torch.int64)
         fam = torch.randint(0, 10, (c,), device=device, generator=g, dtype=torch.int64)
         vals = mutate(fams[fam], 0.10)
         idx = (pos[:, None] + ar[None, :]).reshape(-1)

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
 {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t wsum[CL_THREADS / 64 + 1];
+    __shared__ uint16_t stage[EMIT ? CL_THREADS * 16 : 1]; // offsets of the tile's LMS positions (<= 16 per word)
     uint32_t acc[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) acc[i] = 0;
@@ -272,18 +273,27 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
             }
             if (lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
             __syncthreads();
-            uint32_t off = tile_cnt[tile];
-            for (int i = 0; i < (int)(threadIdx.x >> 6); i++) off += wsum[i];
-            off += inc - cnt;
+            // stage the tile's LMS offsets (13 bits each) in LDS, then write positions and keys coalesced
+            uint32_t loff = inc - cnt;
+            uint32_t tile_total = 0;
+            for (int i = 0; i < CL_THREADS / 64; i++) {
+                if (i < (int)(threadIdx.x >> 6)) loff += wsum[i];
+                tile_total += wsum[i];
+            }
             uint64_t mm = lmsmask;
             while (mm) {
                 int bit = 63 - __clzll(mm); // highest set bit first = smallest position
                 mm &= ~(1ull << bit);
                 uint32_t j = (uint32_t)(62 - bit) >> 1;
-                uint64_t pos = w * 32 + j;
-                lms_pos[off] = (uint32_t)pos;
-                lms_key[off] = kiss_key32(pk, pos);
-                off++;
+                stage[loff++] = (uint16_t)(threadIdx.x * 32 + j);
+            }
+            __syncthreads();
+            const uint64_t gbase = tile_cnt[tile];
+            const uint64_t tbase = tile * (uint64_t)CL_THREADS * 32;
+            for (uint32_t idx = threadIdx.x; idx < tile_total; idx += CL_THREADS) {
+                uint64_t pos = tbase + stage[idx];
+                lms_pos[gbase + idx] = (uint32_t)pos;
+                lms_key[gbase + idx] = kiss_key32(pk, pos);
             }
             __syncthreads();
         }

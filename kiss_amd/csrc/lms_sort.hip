@@ -15,6 +15,8 @@
 // Every step is stable and the initial order is ascending text position, which yields the reference's
 // position tie-break (kiss1_core.hpp:131-133) once the depth D is exhausted.
 #include "kiss_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -239,6 +241,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     uint64_t *K1 = ctx->keyA, *K2 = ctx->keyB;
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[kiss_hip] round 0: items %llu -> survivors %llu in %llu segments\n", (unsigned long long)m_far, (unsigned long long)count, (unsigned long long)nseg);
 
     // ------------------------------ rounds >= 1 ---------------------------------------------
     uint64_t off = ROUND0_BASES;
@@ -313,6 +317,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             KCHECK(hipGetLastError());
         }
         KTRY(read_u64(ctx, d_total, &tot));
+        if (dbg) fprintf(stderr, "[kiss_hip] round off=%llu: items %llu (big %llu) -> survivors %llu in %llu segments\n", (unsigned long long)off, (unsigned long long)count, (unsigned long long)nbig, (unsigned long long)(tot >> 32), (unsigned long long)(tot & 0xFFFFFFFFull));
         std::swap(Sc, Sn);
         std::swap(Gc, Gn);
         std::swap(SSc, SSn);
