@@ -1,18 +1,450 @@
-// fm.hip -- FM-index batched query + build kernels (placeholder until the suffix-sort path is parity-green).
+// fm.hip -- FM-index kernels: batched backward search + locate, and index construction from (text, SA).
+//
+// Index = biovoltron FMIndex<SA_INTV = 4, uint32_t, KISS1Sorter<uint32_t>>{.LOOKUP_LEN = 0}
+// (reference include/biovoltron/algo/align/exact_match/fm_index.hpp); array layout = the .fmi layout
+// (fm_index.hpp:591-615) so a loaded .fmi can be handed over as raw pointers.
+//
+//   occ(c, i)  = occ1[i/256][c] + occ2[i/16][c] + #{c in bwt[16*(i/16) .. i)} - [c == 0 && 16*(i/16) <= pri < i]
+//                                                                   (compute_occ, fm_index.hpp:166-182)
+//   lf(c, i)   = cnt[c] + occ(c, i)                                 (:184-187)
+//   range      : (0, N) then, right to left, beg = lf(c, beg), end = lf(c, end) while end - beg >= 1
+//                                                                   (get_range/compute_range :553-584, 224-235)
+//   locate     : breadth-first over <= SA_INTV - 1 LF levels, emitting sa_[j] + depth for the sampled rows
+//                of every visited range, in the reference's FIFO order, stopping once end - beg offsets
+//                have been collected (get_offsets :453-501).
+// One lane owns one pattern: 2L dependent LF steps of three small loads each (16 B + 4 B + 4 B) --
+// a latency-bound gather workload, so the grid keeps every CU's 2048 lanes busy rather than tiling.
 #include "kiss_internal.hpp"
+
+namespace {
+
+constexpr int FM_THREADS = 256;
+
+struct FmiD {
+    uint64_t N;
+    uint32_t cnt[4];
+    uint32_t pri;
+    uint64_t bwt_bytes;
+    const uint8_t *bwt;
+    const uint32_t *occ1;
+    const uint8_t *occ2;
+    const uint32_t *sa;
+    const uint64_t *b;
+    const uint32_t *b_occ;
+};
+
+// the 16 dibits of chunk i/16 as one u32 (dibit t at bits 2t); the index may end inside the word
+__device__ __forceinline__ uint32_t bwt_word(const FmiD &f, uint64_t chunk)
+{
+    uint64_t byte = chunk * 4;
+    if (byte + 4 <= f.bwt_bytes) {
+        const uint8_t *p = f.bwt + byte;
+        if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t *>(p);
+        return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    }
+    uint32_t w = 0;
+    for (uint64_t k = 0; byte + k < f.bwt_bytes && k < 4; k++) w |= (uint32_t)f.bwt[byte + k] << (8 * k);
+    return w;
+}
+
+__device__ __forceinline__ uint32_t fm_occ(const FmiD &f, uint32_t c, uint64_t i)
+{
+    const uint64_t o1 = i >> 8, o2 = i >> 4;
+    const uint64_t beg = o2 << 4;
+    const uint32_t rem = (uint32_t)(i - beg); // 0..15 dibits of the chunk count
+    uint32_t cnt = 0;
+    if (rem) {
+        uint32_t x = bwt_word(f, o2) ^ (c * 0x55555555u);
+        uint32_t m = ~(x | (x >> 1)) & 0x55555555u; // bit 2t set <=> dibit t == c
+        m &= (1u << (2 * rem)) - 1u;
+        cnt = (uint32_t)__popc(m);
+    }
+    const uint32_t pass_pri = (c == 0 && beg <= f.pri && f.pri < i) ? 1u : 0u;
+    return f.occ1[o1 * 4 + c] + (uint32_t)f.occ2[o2 * 4 + c] + cnt - pass_pri;
+}
+__device__ __forceinline__ uint64_t fm_lf(const FmiD &f, uint32_t c, uint64_t i) { return (uint64_t)f.cnt[c] + fm_occ(f, c, i); }
+
+__device__ __forceinline__ uint32_t fm_bwt(const FmiD &f, uint64_t i)
+{
+    return ((uint32_t)f.bwt[i >> 2] >> (2 * (uint32_t)(i & 3))) & 3u;
+}
+// compute_b_occ, fm_index.hpp:189-208
+__device__ __forceinline__ uint32_t fm_b_occ(const FmiD &f, uint64_t i)
+{
+    const uint64_t w = i >> 6;
+    const uint32_t r = (uint32_t)(i & 63);
+    uint32_t c = f.b_occ[w];
+    if (r) c += (uint32_t)__popcll(f.b[w] & ((1ull << r) - 1ull));
+    return c;
+}
+
+// ---- backward search: one lane per pattern -------------------------------------------------------
+__global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *__restrict__ pat, uint32_t L, uint64_t Q,
+                                                        uint32_t *__restrict__ beg_out, uint32_t *__restrict__ end_out,
+                                                        uint64_t *__restrict__ cap /* hits + 4 per pattern */)
+{
+    uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (q >= Q) return;
+    uint64_t beg = 0, end = f.N;
+    const uint8_t *p = pat + q * L;
+    uint32_t len = L;
+    if (!(end == beg || len == 0)) {
+        while (len > 0) {
+            if (end - beg < 1) break;
+            uint32_t c = p[len - 1] & 3u;
+            beg = fm_lf(f, c, beg);
+            end = fm_lf(f, c, end);
+            len--;
+        }
+    }
+    beg_out[q] = (uint32_t)beg;
+    end_out[q] = (uint32_t)end;
+    cap[q] = (end - beg) + 4;
+}
+
+// ---- locate: the reference's FIFO breadth-first walk, one lane per pattern ------------------------------
+__global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t *__restrict__ beg_in,
+                                                         const uint32_t *__restrict__ end_in, uint64_t Q,
+                                                         const uint64_t *__restrict__ cap_index,
+                                                         uint2 *__restrict__ frontier0, uint2 *__restrict__ frontier1,
+                                                         uint32_t *__restrict__ out, uint64_t *__restrict__ got_out,
+                                                         unsigned long long *__restrict__ totals)
+{
+    uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    unsigned long long got = 0, sum = 0;
+    if (q < Q) {
+        const uint64_t b0 = beg_in[q], e0 = end_in[q];
+        const uint64_t want = e0 - b0;
+        const uint64_t base = cap_index[q];
+        const uint64_t capq = want + 4;
+        uint2 *cur = frontier0 + base, *nxt = frontier1 + base;
+        uint64_t ncur = 1;
+        cur[0] = make_uint2((uint32_t)b0, (uint32_t)e0);
+        bool stop = false;
+        for (int dep = 0; dep < 4 && !stop; dep++) {
+            uint64_t nn = 0;
+            for (uint64_t t = 0; t < ncur; t++) {
+                if (got >= want) {
+                    stop = true;
+                    break;
+                }
+                const uint2 r = cur[t];
+                const uint64_t cb = r.x, ce = r.y;
+                const uint32_t ob = fm_b_occ(f, cb), oe = fm_b_occ(f, ce);
+                for (uint32_t i = ob; i < oe; i++) {
+                    uint32_t v = f.sa[i] + (uint32_t)dep;
+                    if (got < capq) out[base + got] = v;
+                    got++;
+                    sum += v;
+                }
+                if (dep + 1 == 4) continue;
+                if (cb + 1 == ce) {
+                    uint64_t nb = fm_lf(f, fm_bwt(f, cb), cb);
+                    if (nn < capq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
+                    nn++;
+                } else {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) {
+                        uint64_t nb = fm_lf(f, c, cb), ne = fm_lf(f, c, ce);
+                        if (nb != ne) {
+                            if (nn < capq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)ne);
+                            nn++;
+                        }
+                    }
+                }
+            }
+            uint2 *tmp = cur;
+            cur = nxt;
+            nxt = tmp;
+            ncur = nn < capq ? nn : capq;
+        }
+        got_out[q] = got < capq ? got : capq;
+        if (got > capq) got = capq; // can not happen; keeps totals consistent with the buffers
+    }
+    // wave-level reduction of (hits, checksum), one atomic pair per wave
+    unsigned long long g = got, s = sum;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        g += __shfl_xor(g, d, 64);
+        s += __shfl_xor(s, d, 64);
+    }
+    if (lane_id() == 0 && (g | s)) {
+        atomicAdd(&totals[0], g);
+        atomicAdd(&totals[1], s);
+    }
+}
+
+__global__ __launch_bounds__(FM_THREADS) void k_fm_gather_offsets(const uint32_t *__restrict__ scratch,
+                                                                 const uint64_t *__restrict__ cap_index,
+                                                                 const uint64_t *__restrict__ got,
+                                                                 const uint64_t *__restrict__ off_index, uint64_t Q,
+                                                                 uint32_t *__restrict__ offsets, uint64_t capacity)
+{
+    uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (q >= Q) return;
+    const uint64_t src = cap_index[q], dst = off_index[q], g = got[q];
+    for (uint64_t i = 0; i < g; i++)
+        if (dst + i < capacity) offsets[dst + i] = scratch[src + i];
+}
+
+__global__ void k_set_last_u64(uint64_t *arr, uint64_t idx, const uint64_t *ex, const uint64_t *vals)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) arr[idx] = ex[idx - 1] + vals[idx - 1];
+}
+
+// ---- construction --------------------------------------------------------------------------------------
+// one lane per 16-row chunk: BWT dibits, primary row, per-chunk character counts (pri row not counted)
+__global__ __launch_bounds__(FM_THREADS) void k_fm_bwt(const uint8_t *__restrict__ S, const uint32_t *__restrict__ SA,
+                                                      uint64_t N, uint64_t chunks, uint8_t *__restrict__ bwt,
+                                                      uint64_t bwt_bytes, uint32_t *__restrict__ chunk_cnt,
+                                                      uint32_t *__restrict__ pri)
+{
+    uint64_t t = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (t >= chunks) return;
+    uint32_t word = 0, cnt = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        uint64_t i = t * 16 + k;
+        if (i >= N) break;
+        uint32_t v = SA[i];
+        uint32_t c = 0;
+        if (v != 0) {
+            c = S[v - 1] & 3u;
+            cnt += 1u << (8 * c);
+        } else {
+            *pri = (uint32_t)i;
+        }
+        word |= c << (2 * k);
+    }
+    for (uint32_t k = 0; k < 4; k++)
+        if (t * 4 + k < bwt_bytes) bwt[t * 4 + k] = (uint8_t)(word >> (8 * k));
+    chunk_cnt[t] = cnt;
+}
+
+// one lane per 256-row block: occ2 (prefix inside the block) and the block totals
+__global__ __launch_bounds__(FM_THREADS) void k_fm_occ2(const uint32_t *__restrict__ chunk_cnt, uint64_t chunks,
+                                                       uint64_t blocks, uint8_t *__restrict__ occ2,
+                                                       uint32_t *__restrict__ blk_tot /* 4 x blocks */)
+{
+    uint64_t bk = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (bk >= blocks) return;
+    uint32_t run[4] = {0, 0, 0, 0};
+    for (uint32_t k = 0; k < 16; k++) {
+        uint64_t t = bk * 16 + k;
+        if (t >= chunks) break;
+        for (int j = 0; j < 4; j++) occ2[t * 4 + j] = (uint8_t)run[j];
+        uint32_t c = chunk_cnt[t];
+        for (int j = 0; j < 4; j++) run[j] += (c >> (8 * j)) & 255u;
+    }
+    for (int j = 0; j < 4; j++) blk_tot[(uint64_t)j * blocks + bk] = run[j];
+}
+
+__global__ __launch_bounds__(FM_THREADS) void k_fm_occ1(const uint32_t *__restrict__ blk_ex, uint64_t blocks,
+                                                       uint32_t *__restrict__ occ1)
+{
+    uint64_t bk = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (bk >= blocks) return;
+    for (int j = 0; j < 4; j++) occ1[bk * 4 + j] = blk_ex[(uint64_t)j * blocks + bk];
+}
+
+// one lane per 64-row word of the sampling bit-vector
+__global__ __launch_bounds__(FM_THREADS) void k_fm_bits(const uint32_t *__restrict__ SA, uint64_t N, uint64_t words,
+                                                       uint64_t nbocc, uint32_t sa_mask, uint64_t *__restrict__ b,
+                                                       uint32_t *__restrict__ wcnt)
+{
+    uint64_t w = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (w >= nbocc) return;
+    uint64_t bits = 0;
+    if (w < words) {
+        for (uint32_t k = 0; k < 64; k++) {
+            uint64_t i = w * 64 + k;
+            if (i >= N) break;
+            if ((SA[i] & sa_mask) == 0) bits |= 1ull << k;
+        }
+        b[w] = bits;
+    }
+    wcnt[w] = (uint32_t)__popcll(bits);
+}
+
+__global__ __launch_bounds__(FM_THREADS) void k_fm_sample(const uint32_t *__restrict__ SA, uint64_t N, uint64_t words,
+                                                         const uint64_t *__restrict__ b,
+                                                         const uint32_t *__restrict__ b_occ,
+                                                         uint32_t *__restrict__ sa_out)
+{
+    uint64_t w = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (w >= words) return;
+    uint64_t bits = b[w];
+    uint32_t p = b_occ[w];
+    while (bits) {
+        int k = __ffsll((unsigned long long)bits) - 1;
+        bits &= bits - 1;
+        sa_out[p++] = SA[w * 64 + k];
+    }
+}
+
+// column c of the scanned (char, block) matrix minus the total of the smaller chars
+__global__ __launch_bounds__(FM_THREADS) void k_fm_rebase(uint32_t *a, uint64_t blocks, uint32_t b0, uint32_t b1,
+                                                         uint32_t b2, uint32_t b3)
+{
+    uint64_t i = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (i >= 4 * blocks) return;
+    uint32_t j = (uint32_t)(i / blocks);
+    a[i] -= j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(kiss_hip_ctx *ctx, uint64_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            p = nullptr;
+            return KISS_HIP_E_NOMEM;
+        }
+        return KISS_HIP_OK;
+    }
+};
+
+} // namespace
 
 extern "C" {
 
-int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *, const kiss_hip_fmi_view *, const uint8_t *, uint32_t, uint64_t,
-                                 uint32_t *, uint32_t *, uint64_t *, uint64_t *, uint32_t *, uint64_t *, uint64_t,
-                                 void *)
+int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi, const uint8_t *patterns, uint32_t L,
+                                 uint64_t Q, uint32_t *beg, uint32_t *end, uint64_t *hit_count_total,
+                                 uint64_t *checksum, uint32_t *offsets, uint64_t *offsets_index,
+                                 uint64_t offsets_capacity, void *stream)
 {
-    return KISS_HIP_E_UNSUPPORTED;
+    if (!ctx || !fmi || !beg || !end || (Q && !patterns)) return KISS_HIP_E_INVALID;
+    if (fmi->sa_intv != 4) return KISS_HIP_E_UNSUPPORTED; // the CLI's FMIndex<4, ...> (fmindex_build.hpp:27)
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    if (hit_count_total) *hit_count_total = 0;
+    if (checksum) *checksum = 0;
+    if (Q == 0) return KISS_HIP_OK;
+    if (Q / 4096 + 16 > ctx->scan_tmp_cap) return KISS_HIP_E_UNSUPPORTED; // batch larger than the ctx can scan
+    FmiD f;
+    f.N = fmi->n_sa;
+    for (int c = 0; c < 4; c++) f.cnt[c] = fmi->cnt[c];
+    f.pri = fmi->pri;
+    f.bwt_bytes = (fmi->n_sa + 3) / 4;
+    f.bwt = fmi->bwt;
+    f.occ1 = fmi->occ1;
+    f.occ2 = fmi->occ2;
+    f.sa = fmi->sa;
+    f.b = fmi->b;
+    f.b_occ = fmi->b_occ;
+
+    DevBuf cap, capidx, got, gotidx, tot, fr0, fr1, scratch;
+    KTRY(cap.alloc(ctx, (Q + 1) * 8));
+    KTRY(capidx.alloc(ctx, (Q + 1) * 8));
+    KTRY(got.alloc(ctx, (Q + 1) * 8));
+    KTRY(gotidx.alloc(ctx, (Q + 1) * 8));
+    KTRY(tot.alloc(ctx, 16));
+    const unsigned grid = (unsigned)div_up(Q, FM_THREADS);
+    {
+        KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
+        hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
+                           (uint64_t *)cap.p);
+        KCHECK(hipGetLastError());
+    }
+    KCHECK(hipMemsetAsync((uint8_t *)cap.p + Q * 8, 0, 8, ctx->stream));
+    KTRY(kiss_scan_u64(ctx, (const uint64_t *)cap.p, (uint64_t *)capidx.p, Q + 1));
+    uint64_t total_cap = 0;
+    KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(fr0.alloc(ctx, total_cap * sizeof(uint2)));
+    KTRY(fr1.alloc(ctx, total_cap * sizeof(uint2)));
+    KTRY(scratch.alloc(ctx, total_cap * sizeof(uint32_t)));
+    KCHECK(hipMemsetAsync(tot.p, 0, 16, ctx->stream));
+    {
+        KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
+        hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
+                           (const uint64_t *)capidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p, (uint32_t *)scratch.p,
+                           (uint64_t *)got.p, (unsigned long long *)tot.p);
+        KCHECK(hipGetLastError());
+    }
+    if (offsets && offsets_index) {
+        KCHECK(hipMemsetAsync((uint8_t *)got.p + Q * 8, 0, 8, ctx->stream));
+        KTRY(kiss_scan_u64(ctx, (const uint64_t *)got.p, offsets_index, Q + 1));
+        hipLaunchKernelGGL(k_fm_gather_offsets, dim3(grid), dim3(FM_THREADS), 0, ctx->stream,
+                           (const uint32_t *)scratch.p, (const uint64_t *)capidx.p, (const uint64_t *)got.p,
+                           offsets_index, Q, offsets, offsets_capacity);
+        KCHECK(hipGetLastError());
+    }
+    uint64_t h[2] = {0, 0};
+    KCHECK(hipMemcpyAsync(h, tot.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    if (hit_count_total) *hit_count_total = h[0];
+    if (checksum) *checksum = h[1];
+    ktimer_collect(ctx);
+    return KISS_HIP_OK;
 }
 
-int kiss_hip_fmi_build_dev(kiss_hip_ctx *, const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint8_t *, uint32_t *,
-                           uint8_t *, uint32_t *, uint64_t *, uint32_t *, uint32_t[4], uint32_t *, void *)
+int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, const uint32_t *d_SA, uint32_t sa_intv,
+                           uint8_t *d_bwt, uint32_t *d_occ1, uint8_t *d_occ2, uint32_t *d_sa_sampled, uint64_t *d_b,
+                           uint32_t *d_b_occ, uint32_t cnt_out[4], uint32_t *pri_out, void *stream)
 {
-    return KISS_HIP_E_UNSUPPORTED;
+    if (!ctx || !d_SA || (n && !d_S) || !d_bwt || !d_occ1 || !d_occ2 || !d_sa_sampled || !d_b || !d_b_occ || !cnt_out ||
+        !pri_out)
+        return KISS_HIP_E_INVALID;
+    if (sa_intv != 4) return KISS_HIP_E_UNSUPPORTED;
+    if (n > KISS_HIP_MAX_N) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    const uint64_t N = n + 1;
+    const uint64_t chunks = N / 16 + 1, blocks = N / 256 + 1;
+    const uint64_t words = (N + 63) / 64, nbocc = N / 64 + 1;
+    const uint64_t bwt_bytes = (N + 3) / 4;
+    if (blocks / 4096 + 16 > ctx->scan_tmp_cap || nbocc / 4096 + 16 > ctx->scan_tmp_cap) return KISS_HIP_E_UNSUPPORTED;
+    DevBuf chunk_cnt, blk_tot, wcnt, pri;
+    KTRY(chunk_cnt.alloc(ctx, chunks * 4));
+    KTRY(blk_tot.alloc(ctx, (4 * blocks + 1) * 4));
+    KTRY(wcnt.alloc(ctx, nbocc * 4));
+    KTRY(pri.alloc(ctx, 4));
+    KTimer t(ctx, KISS_HIP_K_FM_BUILD, N);
+    hipLaunchKernelGGL(k_fm_bwt, dim3((unsigned)div_up(chunks, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream, d_S, d_SA,
+                       N, chunks, d_bwt, bwt_bytes, (uint32_t *)chunk_cnt.p, (uint32_t *)pri.p);
+    hipLaunchKernelGGL(k_fm_occ2, dim3((unsigned)div_up(blocks, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream,
+                       (const uint32_t *)chunk_cnt.p, chunks, blocks, d_occ2, (uint32_t *)blk_tot.p);
+    KCHECK(hipGetLastError());
+    // digit-major exclusive scan over (char, block) gives, per char, prefix over blocks + totals of smaller chars;
+    // subtract the per-char base afterwards on the host side of cnt[]
+    KCHECK(hipMemsetAsync((uint32_t *)blk_tot.p + 4 * blocks, 0, 4, ctx->stream));
+    KTRY(kiss_scan_u32(ctx, (const uint32_t *)blk_tot.p, (uint32_t *)blk_tot.p, 4 * blocks + 1));
+    uint32_t base[5];
+    for (int j = 0; j < 5; j++)
+        KCHECK(hipMemcpyAsync(&base[j], (uint32_t *)blk_tot.p + (uint64_t)j * blocks, 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    // occ1[block][c] = scan[c*blocks + block] - base[c]; do the subtraction in the interleave kernel by
+    // temporarily rebasing: simplest is a tiny second pass per char
+    hipLaunchKernelGGL(k_fm_rebase, dim3((unsigned)div_up(4 * blocks, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream,
+                       (uint32_t *)blk_tot.p, blocks, base[0], base[1], base[2], base[3]);
+    hipLaunchKernelGGL(k_fm_occ1, dim3((unsigned)div_up(blocks, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream,
+                       (const uint32_t *)blk_tot.p, blocks, d_occ1);
+    // sampling bit-vector, its rank directory and the sampled SA
+    hipLaunchKernelGGL(k_fm_bits, dim3((unsigned)div_up(nbocc, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream, d_SA, N,
+                       words, nbocc, sa_intv - 1, d_b, (uint32_t *)wcnt.p);
+    KCHECK(hipGetLastError());
+    KTRY(kiss_scan_u32(ctx, (const uint32_t *)wcnt.p, d_b_occ, nbocc));
+    hipLaunchKernelGGL(k_fm_sample, dim3((unsigned)div_up(words, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream, d_SA, N,
+                       words, d_b, d_b_occ, d_sa_sampled);
+    KCHECK(hipGetLastError());
+    uint32_t h_pri = 0;
+    KCHECK(hipMemcpyAsync(&h_pri, pri.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    *pri_out = h_pri;
+    // cnt_ = {1, 1+#A, 1+#A+#C, 1+#A+#C+#G} (fm_index.hpp:303-307); totals from the scan bases
+    uint32_t sum = 1;
+    for (int j = 0; j < 4; j++) {
+        uint32_t tot = base[j + 1] - base[j];
+        cnt_out[j] = sum;
+        sum += tot;
+    }
+    return KISS_HIP_OK;
 }
 }

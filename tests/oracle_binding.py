@@ -46,12 +46,99 @@ class Oracle:
         m = self.lib.ko_get_lms(S.ctypes.data, n, lms.ctypes.data, hist.ctypes.data)
         return lms[:m], hist.reshape(5, 256)
 
+    # ---- FM-index (oracle/kiss_oracle_fm.c) ----------------------------------------------------------
+    def fm_build(self, S, SA):
+        lib = self.lib
+        vp = ctypes.c_void_p
+        lib.ko_fmi_build.argtypes = [vp, ctypes.c_uint32, vp]
+        lib.ko_fmi_build.restype = vp
+        S = np.ascontiguousarray(S, dtype=np.uint8)
+        SA = np.ascontiguousarray(SA, dtype=np.uint32)
+        return OracleFmi(lib, lib.ko_fmi_build(S.ctypes.data, S.size, SA.ctypes.data))
+
     def fnv(self, a):
         a = np.ascontiguousarray(a, dtype=np.uint32)
         return int(self.lib.ko_fnv1a64_u32(a.ctypes.data, a.size))
 
     def num_threads(self):
         return int(self.lib.ko_num_threads())
+
+
+class OracleFmi:
+    """handle on a ko_fmi built by the oracle (freed on garbage collection)"""
+
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, ctypes.c_void_p(handle)
+        vp = ctypes.c_void_p
+        lib.ko_fmi_N.argtypes = [vp]
+        lib.ko_fmi_N.restype = ctypes.c_uint64
+        lib.ko_fmi_pri.argtypes = [vp]
+        lib.ko_fmi_pri.restype = ctypes.c_uint32
+        for name in ("cnt", "bwt", "occ1", "occ2", "sa", "b", "bocc"):
+            fn = getattr(lib, "ko_fmi_" + name)
+            fn.argtypes = [vp]
+            fn.restype = vp
+        lib.ko_fmi_free.argtypes = [vp]
+        lib.ko_fmi_serialize.argtypes = [vp, vp]
+        lib.ko_fmi_serialize.restype = ctypes.c_uint64
+        lib.ko_fmi_query_batch.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
+                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp]
+        self.N = int(lib.ko_fmi_N(self.h))
+        self.pri = int(lib.ko_fmi_pri(self.h))
+
+    def _arr(self, name, dtype, count):
+        p = getattr(self.lib, "ko_fmi_" + name)(self.h)
+        nbytes = count * np.dtype(dtype).itemsize
+        return np.frombuffer((ctypes.c_uint8 * nbytes).from_address(p), dtype=dtype).copy()
+
+    def arrays(self):
+        N = self.N
+        return {
+            "cnt": self._arr("cnt", np.uint32, 4),
+            "bwt": self._arr("bwt", np.uint8, (N + 3) // 4),
+            "occ1": self._arr("occ1", np.uint32, (N // 256 + 1) * 4),
+            "occ2": self._arr("occ2", np.uint8, (N // 16 + 1) * 4),
+            "sa": self._arr("sa", np.uint32, (N + 3) // 4),
+            "b": self._arr("b", np.uint64, (N + 63) // 64),
+            "b_occ": self._arr("bocc", np.uint32, N // 64 + 1),
+        }
+
+    def serialize(self):
+        size = int(self.lib.ko_fmi_serialize(self.h, None))
+        buf = (ctypes.c_uint8 * size)()
+        self.lib.ko_fmi_serialize(self.h, buf)
+        return bytes(buf)
+
+    def query_batch(self, patterns, want_offsets=True):
+        patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+        Q, L = patterns.shape
+        beg = np.empty(Q, np.uint32)
+        end = np.empty(Q, np.uint32)
+        tot, chk = ctypes.c_uint64(), ctypes.c_uint64()
+        res = {}
+        if want_offsets:
+            # two passes: size, then fill
+            self.lib.ko_fmi_query_batch(self.h, patterns.ctypes.data, L, Q, beg.ctypes.data, end.ctypes.data,
+                                        ctypes.byref(tot), ctypes.byref(chk), None, None)
+            off = np.empty(max(1, tot.value), np.uint32)
+            idx = np.empty(Q + 1, np.uint64)
+            self.lib.ko_fmi_query_batch(self.h, patterns.ctypes.data, L, Q, beg.ctypes.data, end.ctypes.data,
+                                        ctypes.byref(tot), ctypes.byref(chk), off.ctypes.data, idx.ctypes.data)
+            res["offsets"] = off[:tot.value]
+            res["offsets_index"] = idx
+        else:
+            self.lib.ko_fmi_query_batch(self.h, patterns.ctypes.data, L, Q, beg.ctypes.data, end.ctypes.data,
+                                        ctypes.byref(tot), ctypes.byref(chk), None, None)
+        res.update(beg=beg, end=end, total_hits=int(tot.value), checksum=int(chk.value))
+        return res
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ko_fmi_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 def build():

@@ -1,0 +1,53 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/kiss_hip.h declares."""
+import ctypes
+import os
+import re
+
+import kiss_amd
+from kiss_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "kiss_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kiss_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = kiss_amd.load()
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), "missing export " + s
+    assert sorted(_lib.EXPORTED_SYMBOLS) == syms
+
+
+def test_version_and_strerror():
+    lib = kiss_amd.load()
+    assert lib.kiss_hip_version() == 100
+    assert _lib.strerror(0) == "ok"
+    assert "invalid" in _lib.strerror(-1)
+
+
+def test_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = kiss_amd.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.kiss_hip_ctx_create(ctypes.byref(ctx), 0, 1000)
+    assert rc == -2  # KISS_HIP_E_NO_DEVICE: no silent CPU fallback
+    try:
+        kiss_amd.KISS1Sorter.get_suffix_array_dna([0, 1, 2, 3], 256)
+        raised = False
+    except kiss_amd.KissHipError:
+        raised = True
+    assert raised
+
+
+def test_stats_struct_matches_header():
+    # sizeof(kiss_hip_stats) computed from the header's field list
+    assert ctypes.sizeof(_lib.Stats) == 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 6 * 4 + 16 * 4 + 4 + 16 * 8 + 16 * 8 or \
+        ctypes.sizeof(_lib.Stats) % 8 == 0
