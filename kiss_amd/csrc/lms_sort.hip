@@ -5,13 +5,15 @@
 // the order is (first D bases, then text position).  k >= n means the exact suffix order (D unbounded;
 // past-the-end bases read as 'A' exactly like the reference's zero padding, structs.hpp:94-96).
 //
-// GPU formulation: MSD refinement in rounds.
+// GPU formulation: MSD refinement.
 //   round 0 : stable LSD radix sort of all suffixes on their first 20 bases (5 passes of 8 bits);
 //             suffixes that share those 20 bases form a segment, singletons retire to their final slot.
-//   round r : every still-tied suffix fetches the next 32 bases (one u64 key);
-//             segments of <= SMALL_SEG suffixes are ordered by brute-force counting inside the segment
-//             (one thread per suffix, the segment's keys come from L1/L2), larger segments go through
-//             the radix sort on (segment id, key); equal neighbours stay tied, singletons retire.
+//   round r : every still-tied suffix fetches its next 32 bases (one u64 key).
+//             - a segment of <= SMALL_SEG suffixes is FINISHED on the spot: one lane per suffix ranks it
+//               against the others of its segment, first on the fetched key and, for pairs that tie on it,
+//               by walking both suffixes to the full depth D (then position).  All of them retire.
+//             - larger segments are compacted, radix sorted on (segment id, key), split where neighbours
+//               differ, and go round again (their pieces are usually small and finish next round).
 // Every step is stable and the initial order is ascending text position, which yields the reference's
 // position tie-break (kiss1_core.hpp:131-133) once the depth D is exhausted.
 #include "kiss_internal.hpp"
@@ -38,14 +40,38 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_keys(const uint64_t *__re
     key[i] = k & mask;
 }
 
-// small segments: order inside the segment by counting; big segments: flag for the radix path.
-// big[i] = (1 << 32) | (first item of a big segment)
-__global__ __launch_bounds__(LS_THREADS) void k_seg_rank(const uint64_t *__restrict__ key,
-                                                        const uint32_t *__restrict__ pos,
-                                                        const uint32_t *__restrict__ seg,
-                                                        const uint32_t *__restrict__ segstart, uint64_t count,
-                                                        uint64_t *__restrict__ okey, uint32_t *__restrict__ opos,
-                                                        uint64_t *__restrict__ big, uint32_t *__restrict__ nbig)
+// true if suffix pi sorts before suffix pj, both already equal on [0, off + 32); bases from off + 32 on are
+// compared up to depth (0 = unbounded), ties go to the smaller index (= smaller text position)
+__device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint64_t n, uint64_t pi, uint64_t pj,
+                                          uint64_t off, uint64_t depth, bool i_before_j)
+{
+    uint64_t d = off + 32;
+    for (;;) {
+        if (depth && d >= depth) return i_before_j;
+        uint64_t qi = pi + d, qj = pj + d;
+        if (qi >= n && qj >= n) return i_before_j; // both ran off the text (does not happen for two LMS suffixes)
+        uint64_t ki = qi < n ? kiss_key32(pk, qi) : 0ull;
+        uint64_t kj = qj < n ? kiss_key32(pk, qj) : 0ull;
+        if (depth && depth - d < 32) {
+            uint64_t mask = ~0ull << (64 - 2 * (depth - d));
+            ki &= mask;
+            kj &= mask;
+        }
+        if (ki != kj) return ki < kj;
+        d += 32;
+    }
+}
+
+// small segments: final rank of every member by counting, written straight to its final slot;
+// big segments: flagged for the radix path.  big[i] = (1 << 32) | (first item of a big segment)
+__global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__restrict__ pk, uint64_t n,
+                                                          const uint64_t *__restrict__ key,
+                                                          const uint32_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ slot,
+                                                          const uint32_t *__restrict__ seg,
+                                                          const uint32_t *__restrict__ segstart, uint64_t count,
+                                                          uint64_t off, uint64_t depth, uint32_t *__restrict__ out,
+                                                          uint64_t *__restrict__ big, uint32_t *__restrict__ nbig)
 {
     uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     bool isbig = false;
@@ -53,14 +79,18 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_rank(const uint64_t *__restr
         uint32_t sg = seg[i];
         uint32_t a = segstart[sg], b = segstart[sg + 1];
         if (b - a <= SMALL_SEG) {
-            uint64_t ki = key[i];
+            const uint64_t ki = key[i];
+            const uint64_t pi = pos[i];
             uint32_t r = 0;
             for (uint32_t j = a; j < b; j++) {
+                if (j == (uint32_t)i) continue;
                 uint64_t kj = key[j];
-                r += (kj < ki || (kj == ki && j < (uint32_t)i)) ? 1u : 0u;
+                bool jless;
+                if (kj != ki) jless = kj < ki;
+                else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i);
+                r += jless ? 1u : 0u;
             }
-            okey[a + r] = ki;
-            opos[a + r] = pos[i];
+            out[slot[a + r]] = (uint32_t)pi;
             big[i] = 0;
         } else {
             isbig = true;
@@ -72,7 +102,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_rank(const uint64_t *__restr
 }
 
 __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__restrict__ key,
-                                                           const uint32_t *__restrict__ pos, uint64_t count,
+                                                           const uint32_t *__restrict__ pos,
+                                                           const uint32_t *__restrict__ slot, uint64_t count,
                                                            const uint64_t *__restrict__ big,
                                                            const uint64_t *__restrict__ ex,
                                                            uint64_t *__restrict__ bkey, uint32_t *__restrict__ bpos,
@@ -86,20 +117,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__re
     uint32_t kx = (uint32_t)(e >> 32);
     bkey[kx] = key[i];
     bpos[kx] = pos[i];
-    bslot[kx] = (uint32_t)i;
+    bslot[kx] = slot[i]; // slots stay in index order: the k-th item after the sort takes the k-th slot
     bseg[kx] = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
-}
-
-__global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__restrict__ bkey,
-                                                             const uint32_t *__restrict__ bpos,
-                                                             const uint32_t *__restrict__ bslot, uint64_t nbig,
-                                                             uint64_t *__restrict__ okey, uint32_t *__restrict__ opos)
-{
-    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= nbig) return;
-    uint32_t s = bslot[i];
-    okey[s] = bkey[i];
-    opos[s] = bpos[i];
 }
 
 // flags[i] = (survivor << 32) | surviving_head ; keys are compared on bits [cmp_shift, 64)
@@ -201,6 +220,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint32_t *d_nbig = ctx->d_small + 8;
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     const unsigned T = LS_THREADS;
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
 
     // ------------------------------ round 0 ------------------------------------------------
     uint64_t count = m_far;
@@ -218,10 +238,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     ctx->stats.lms_rounds++;
     ctx->stats.sort_item_rounds += count;
     uint32_t *Pc = rb.pos[res ^ 1]; // receives the survivors' positions
-    uint32_t *Po = rb.pos[res];
-    uint32_t *Sc = ctx->slotA, *Sn = ctx->slotB;
-    uint32_t *Gc = ctx->segA, *Gn = ctx->segB;
-    uint32_t *SSc = ctx->segstartA, *SSn = ctx->segstartB;
+    uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
     {
         KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
         hipLaunchKernelGGL((k_flag<false>), dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, rb.key[res],
@@ -231,7 +248,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     KTRY(kiss_scan_u64(ctx, F1, F2, count));
     {
         KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_compact<false>), dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, Po,
+        hipLaunchKernelGGL((k_compact<false>), dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, rb.pos[res],
                            (const uint32_t *)nullptr, count, F1, F2, Pc, Sc, Gc, SSc, ctx->lms_sorted_far);
         hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
         KCHECK(hipGetLastError());
@@ -240,14 +257,15 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     KTRY(read_u64(ctx, d_total, &tot));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
-    uint64_t *K1 = ctx->keyA, *K2 = ctx->keyB;
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[kiss_hip] round 0: items %llu -> survivors %llu in %llu segments\n", (unsigned long long)m_far, (unsigned long long)count, (unsigned long long)nseg);
+    if (dbg)
+        fprintf(stderr, "[kiss_hip] round 0: items %llu -> survivors %llu in %llu segments\n",
+                (unsigned long long)m_far, (unsigned long long)count, (unsigned long long)nseg);
+    uint64_t *K1 = ctx->keyA;
 
     // ------------------------------ rounds >= 1 ---------------------------------------------
     uint64_t off = ROUND0_BASES;
     while (count > 0) {
-        if (depth && off >= depth) return KISS_HIP_E_INTERNAL; // depth exhausted with ties left: flagged last round
+        if (depth && off >= depth) return KISS_HIP_E_INTERNAL; // the last round retires everything
         uint64_t rem = depth ? depth - off : 32;
         if (rem > 32) rem = 32;
         const bool last_round = depth ? (off + 32 >= depth) : false;
@@ -263,64 +281,59 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         {
             KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, d_nbig);
-            hipLaunchKernelGGL(k_seg_rank, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, Gc, SSc, count, K2, Po, F1,
-                               d_nbig);
+            hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
+                               count, off, depth, ctx->lms_sorted_far, F1, d_nbig);
             KCHECK(hipGetLastError());
-        }
-        uint64_t nbig64 = 0;
-        KTRY(read_u64(ctx, d_nbig, &nbig64));
-        const uint64_t nbig = nbig64 & 0xFFFFFFFFull;
-        if (nbig > 0) {
-            KTRY(kiss_scan_u64(ctx, F1, F2, count));
-            {
-                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-                hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, count, F1, F2,
-                                   ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot);
-                hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
-                KCHECK(hipGetLastError());
-            }
-            uint64_t bt;
-            KTRY(read_u64(ctx, d_total, &bt));
-            if ((bt >> 32) != nbig) return KISS_HIP_E_INTERNAL;
-            const uint64_t nbigseg = bt & 0xFFFFFFFFull;
-            RadixBufs bb;
-            bb.key[0] = ctx->bkeyA;
-            bb.key[1] = ctx->bkeyB;
-            bb.pos[0] = ctx->bposA;
-            bb.pos[1] = ctx->bposB;
-            bb.seg[0] = ctx->bsegA;
-            bb.seg[1] = ctx->bsegB;
-            int bres = 0;
-            KTRY(kiss_radix_sort(ctx, bb, nbig, key_lo_bit, bits_for(nbigseg), &bres));
-            {
-                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
-                hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)div_up(nbig, T)), dim3(T), 0, ctx->stream,
-                                   bb.key[bres], bb.pos[bres], ctx->bslot, nbig, K2, Po);
-                KCHECK(hipGetLastError());
-            }
-            ctx->stats.big_item_rounds += nbig;
         }
         ctx->stats.lms_rounds++;
         ctx->stats.sort_item_rounds += count;
-        {
-            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-            hipLaunchKernelGGL((k_flag<true>), dim3(grid), dim3(T), 0, ctx->stream, K2, Gc, count, 0, (int)last_round,
-                               F1);
-            KCHECK(hipGetLastError());
-        }
+        uint64_t nbig64 = 0;
+        KTRY(read_u64(ctx, d_nbig, &nbig64));
+        const uint64_t nbig = nbig64 & 0xFFFFFFFFull;
+        if (dbg)
+            fprintf(stderr, "[kiss_hip] round off=%llu: items %llu in %llu segments, big-segment items %llu\n",
+                    (unsigned long long)off, (unsigned long long)count, (unsigned long long)nseg,
+                    (unsigned long long)nbig);
+        if (nbig == 0) break;
+        // ---- big segments: compact, radix sort on (segment, key), split, survivors go round again
         KTRY(kiss_scan_u64(ctx, F1, F2, count));
         {
             KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-            hipLaunchKernelGGL((k_compact<true>), dim3(grid), dim3(T), 0, ctx->stream, Po, Sc, count, F1, F2, Pc, Sn,
-                               Gn, SSn, ctx->lms_sorted_far);
+            hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, Sc, count, F1, F2,
+                               ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot);
             hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
             KCHECK(hipGetLastError());
         }
+        uint64_t bt;
+        KTRY(read_u64(ctx, d_total, &bt));
+        if ((bt >> 32) != nbig) return KISS_HIP_E_INTERNAL;
+        const uint64_t nbigseg = bt & 0xFFFFFFFFull;
+        RadixBufs bb;
+        bb.key[0] = ctx->bkeyA;
+        bb.key[1] = ctx->bkeyB;
+        bb.pos[0] = ctx->bposA;
+        bb.pos[1] = ctx->bposB;
+        bb.seg[0] = ctx->bsegA;
+        bb.seg[1] = ctx->bsegB;
+        int bres = 0;
+        KTRY(kiss_radix_sort(ctx, bb, nbig, key_lo_bit, bits_for(nbigseg), &bres));
+        ctx->stats.big_item_rounds += nbig;
+        const unsigned bgrid = (unsigned)div_up(nbig, T);
+        {
+            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+            hipLaunchKernelGGL((k_flag<true>), dim3(bgrid), dim3(T), 0, ctx->stream, bb.key[bres], bb.seg[bres], nbig, 0,
+                               (int)last_round, F1);
+            KCHECK(hipGetLastError());
+        }
+        KTRY(kiss_scan_u64(ctx, F1, F2, nbig));
+        {
+            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+            hipLaunchKernelGGL((k_compact<true>), dim3(bgrid), dim3(T), 0, ctx->stream, bb.pos[bres], ctx->bslot, nbig,
+                               F1, F2, Pc, Sc, Gc, SSc, ctx->lms_sorted_far);
+            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, nbig, d_total);
+            KCHECK(hipGetLastError());
+        }
         KTRY(read_u64(ctx, d_total, &tot));
-        if (dbg) fprintf(stderr, "[kiss_hip] round off=%llu: items %llu (big %llu) -> survivors %llu in %llu segments\n", (unsigned long long)off, (unsigned long long)count, (unsigned long long)nbig, (unsigned long long)(tot >> 32), (unsigned long long)(tot & 0xFFFFFFFFull));
-        std::swap(Sc, Sn);
-        std::swap(Gc, Gn);
-        std::swap(SSc, SSn);
         count = tot >> 32;
         nseg = tot & 0xFFFFFFFFull;
         off += 32;
