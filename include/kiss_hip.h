@@ -140,6 +140,11 @@ int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, 
 int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, uint32_t *lms_sorted,
                                    uint64_t *counts);
 
+/* Test hooks (used by tests/ only): the library's stable LSD radix sort on bits [key_lo_bit, 64) of keys with a
+ * 32-bit payload, and its exclusive u32 scan, run on caller data in host memory (count <= ctx LMS capacity). */
+int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, uint64_t count, int key_lo_bit);
+int kiss_hip_debug_scan_u32(kiss_hip_ctx *ctx, uint32_t *data, uint64_t count);
+
 /* ---- FM-index (biovoltron FMIndex<4,uint32_t,...>{LOOKUP_LEN=0}) --------------- */
 /* Raw views of the arrays of the .fmi layout (fm_index.hpp:591-615).
  * For the *_dev call every pointer is a device pointer. */

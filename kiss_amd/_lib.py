@@ -86,6 +86,8 @@ def load():
     lib.kiss_hip_ctx_suffix_sort_dna_u32.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp]
     lib.kiss_hip_ctx_suffix_sort_dna_u32_dev.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, vp]
     lib.kiss_hip_ctx_get_stage_outputs.argtypes = [vp, vp, vp, vp]
+    lib.kiss_hip_debug_radix_sort.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_int]
+    lib.kiss_hip_debug_scan_u32.argtypes = [vp, vp, ctypes.c_uint64]
     lib.kiss_hip_fmi_query_batch_dev.argtypes = [
         vp, ctypes.POINTER(FmiView), vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp, ctypes.c_uint64, vp]
@@ -96,7 +98,8 @@ def load():
                  "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
                  "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32",
                  "kiss_hip_ctx_suffix_sort_dna_u32_dev", "kiss_hip_ctx_get_stage_outputs",
-                 "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev"):
+                 "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev", "kiss_hip_debug_radix_sort",
+                 "kiss_hip_debug_scan_u32"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib
@@ -112,4 +115,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_ctx_set_profiling", "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
     "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32_dev",
     "kiss_hip_ctx_get_stage_outputs", "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
+    "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
 ]

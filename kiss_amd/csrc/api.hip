@@ -99,7 +99,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
     ctx->n = n;
     ctx->m = ctx->m_far = 0;
     if (n == 0) { // kiss1_core.hpp:237-238
-        KCHECK(hipMemsetAsync(d_SA, 0, sizeof(uint32_t), ctx->stream));
+        KTRY(kiss_zero_u32(ctx, d_SA, 1));
         KCHECK(hipStreamSynchronize(ctx->stream));
         return KISS_HIP_OK;
     }
@@ -374,6 +374,40 @@ int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int a
     rc = kiss_hip_ctx_suffix_sort_dna_u32(ctx, S, n, k, algo, SA);
     kiss_hip_ctx_destroy(ctx);
     return rc;
+}
+
+/* ---- test hooks: the sorting / scanning primitives on caller data (host pointers) ---------------------- */
+int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, uint64_t count, int key_lo_bit)
+{
+    if (!ctx || !keys || !pos || count > ctx->m_cap) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = ctx->own_stream;
+    KCHECK(hipMemcpy(ctx->keyA, keys, count * 8, hipMemcpyHostToDevice));
+    KCHECK(hipMemcpy(ctx->posA, pos, count * 4, hipMemcpyHostToDevice));
+    RadixBufs rb;
+    rb.key[0] = ctx->keyA;
+    rb.key[1] = ctx->keyB;
+    rb.pos[0] = ctx->posA;
+    rb.pos[1] = ctx->posB;
+    rb.seg[0] = rb.seg[1] = nullptr;
+    int res = 0;
+    KTRY(kiss_radix_sort(ctx, rb, count, key_lo_bit, 0, &res));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    KCHECK(hipMemcpy(keys, rb.key[res], count * 8, hipMemcpyDeviceToHost));
+    KCHECK(hipMemcpy(pos, rb.pos[res], count * 4, hipMemcpyDeviceToHost));
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_debug_scan_u32(kiss_hip_ctx *ctx, uint32_t *data, uint64_t count)
+{
+    if (!ctx || !data || count > ctx->m_cap) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = ctx->own_stream;
+    KCHECK(hipMemcpy(ctx->posA, data, count * 4, hipMemcpyHostToDevice));
+    KTRY(kiss_scan_u32(ctx, ctx->posA, ctx->posB, count));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    KCHECK(hipMemcpy(data, ctx->posB, count * 4, hipMemcpyDeviceToHost));
+    return KISS_HIP_OK;
 }
 
 int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, uint32_t *lms_sorted, uint64_t *counts)

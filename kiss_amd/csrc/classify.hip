@@ -314,7 +314,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n)
 {
     const uint64_t words = div_up(n, 32) + 4; // spare zero words: key loads may touch w+1 past the end
-    if (words > ctx->pk_words) return KISS_HIP_E_INTERNAL;
+    if (words > ctx->pk_words) return KINTERNAL();
     KTimer t(ctx, KISS_HIP_K_PACK, n);
     hipLaunchKernelGGL(k_pack, dim3((unsigned)div_up(words, 256)), dim3(256), 0, ctx->stream, d_S, n, ctx->pk, words);
     KCHECK(hipGetLastError());
@@ -325,7 +325,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
 {
     const uint64_t words = div_up(n, 32);
     const uint64_t tiles = div_up(words, CL_THREADS);
-    if (tiles > ctx->n_tiles_cap) return KISS_HIP_E_INTERNAL;
+    if (tiles > ctx->n_tiles_cap) return KINTERNAL();
     // far LMS suffixes: p + depth <= n  (all of them when unbounded)
     uint64_t far_limit = ~0ull;
     bool none_far = false;
@@ -333,7 +333,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
         if (depth > n) none_far = true;
         else far_limit = n - depth;
     }
-    KCHECK(hipMemsetAsync(ctx->d_counts, 0, 16 * sizeof(uint32_t), ctx->stream));
+    KTRY(kiss_zero_u32(ctx, ctx->d_counts, 16));
     {
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
         hipLaunchKernelGGL(k_tile_gp, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words,

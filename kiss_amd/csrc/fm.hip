@@ -351,7 +351,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
                            (uint64_t *)cap.p);
         KCHECK(hipGetLastError());
     }
-    KCHECK(hipMemsetAsync((uint8_t *)cap.p + Q * 8, 0, 8, ctx->stream));
+    KTRY(kiss_zero_u32(ctx, (uint8_t *)cap.p + Q * 8, 2));
     KTRY(kiss_scan_u64(ctx, (const uint64_t *)cap.p, (uint64_t *)capidx.p, Q + 1));
     uint64_t total_cap = 0;
     KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -359,7 +359,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     KTRY(fr0.alloc(ctx, total_cap * sizeof(uint2)));
     KTRY(fr1.alloc(ctx, total_cap * sizeof(uint2)));
     KTRY(scratch.alloc(ctx, total_cap * sizeof(uint32_t)));
-    KCHECK(hipMemsetAsync(tot.p, 0, 16, ctx->stream));
+    KTRY(kiss_zero_u32(ctx, tot.p, 4));
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
         hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
@@ -368,7 +368,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
         KCHECK(hipGetLastError());
     }
     if (offsets && offsets_index) {
-        KCHECK(hipMemsetAsync((uint8_t *)got.p + Q * 8, 0, 8, ctx->stream));
+        KTRY(kiss_zero_u32(ctx, (uint8_t *)got.p + Q * 8, 2));
         KTRY(kiss_scan_u64(ctx, (const uint64_t *)got.p, offsets_index, Q + 1));
         hipLaunchKernelGGL(k_fm_gather_offsets, dim3(grid), dim3(FM_THREADS), 0, ctx->stream,
                            (const uint32_t *)scratch.p, (const uint64_t *)capidx.p, (const uint64_t *)got.p,
@@ -413,7 +413,7 @@ int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, co
     KCHECK(hipGetLastError());
     // digit-major exclusive scan over (char, block) gives, per char, prefix over blocks + totals of smaller chars;
     // subtract the per-char base afterwards on the host side of cnt[]
-    KCHECK(hipMemsetAsync((uint32_t *)blk_tot.p + 4 * blocks, 0, 4, ctx->stream));
+    KTRY(kiss_zero_u32(ctx, (uint32_t *)blk_tot.p + 4 * blocks, 1));
     KTRY(kiss_scan_u32(ctx, (const uint32_t *)blk_tot.p, (uint32_t *)blk_tot.p, 4 * blocks + 1));
     uint32_t base[5];
     for (int j = 0; j < 5; j++)

@@ -20,6 +20,8 @@
 // The LMS suffixes are never copied into SA (put_lms_suffix disappears): the L sweep reads them from
 // the sorted LMS array, and the S sweep overwrites every S-type slot anyway (induced_clear disappears).
 #include "kiss_internal.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -250,10 +252,10 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         *chain_done = true;
     } else {
         const uint64_t tiles = div_up(N, IN_TILE);
-        if (4 * tiles + 1 > ctx->ind_tiles_cap) return KISS_HIP_E_INTERNAL;
+        if (4 * tiles + 1 > ctx->ind_tiles_cap) return KINTERNAL();
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
-            KCHECK(hipMemsetAsync(ctx->ind_counts + 4 * tiles, 0, sizeof(uint32_t), ctx->stream));
+            KTRY(kiss_zero_u32(ctx, ctx->ind_counts + 4 * tiles, 1));
             hipLaunchKernelGGL(k_induce_count, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
                                srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles);
             KCHECK(hipGetLastError());
@@ -271,7 +273,289 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         KCHECK(hipStreamSynchronize(ctx->stream));
         for (int c = 0; c < 4; c++) tot[c] = ctx->h_pinned[c];
     }
+    if (getenv("KISS_HIP_DEBUG"))
+        fprintf(stderr, "[kiss_hip] pass dir=%d beg=%lld N=%llu mask=%x self=%d -> %llu,%llu,%llu,%llu\n", sw.dir, (long long)beg,
+                (unsigned long long)N, emitmask, selfclass, (unsigned long long)tot[0], (unsigned long long)tot[1],
+                (unsigned long long)tot[2], (unsigned long long)tot[3]);
     for (int c = 0; c < 4; c++) sw.pos[c] += (int64_t)sw.dir * (int64_t)tot[c];
+    return KISS_HIP_OK;
+}
+
+// ---- chain collapse ---------------------------------------------------------------------------------------
+// A segment that appends to itself (L-part(c) feeding L-part(c): runs of one base) is a chain of rounds,
+// round t+1 being the items of round t that are preceded by base c again.  Once a round is small the rest
+// of the chain is computed in closed form instead of round by round:
+//   every item v of the current round has a run length r(v) = number of c's right before v (capped at R);
+//   it contributes v-1 .. v-r to rounds 1 .. r, and the round-t block holds the items with r >= t in their
+//   original order  ->  a stable sort of the pairs (t, item) by t (two 8-bit radix passes);
+//   the last element of a chain appends its predecessor to another bucket during round r(v), so those
+//   terminal items are ordered by (r, item) inside their bucket  ->  one more small stable sort.
+// Items whose run reaches the cap R continue from the last block in the next call.
+constexpr uint64_t COLLAPSE_N = 1ull << 21;
+constexpr uint32_t COLLAPSE_RCAP = 65535;
+constexpr int CH_THREADS = 256;
+
+__device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, uint64_t v, uint32_t c, uint32_t cap)
+{
+    const uint64_t pat = (uint64_t)c * 0x5555555555555555ull;
+    uint32_t r = 0;
+    uint64_t p = v; // bases before v still to test: indices < p
+    while (p > 0 && r < cap) {
+        const uint64_t q = p - 1;
+        const uint32_t in = (uint32_t)(q & 31u) + 1u; // bases of this word with index <= q
+        const uint64_t y = (pk[q >> 5] ^ pat) >> (62u - 2u * (uint32_t)(q & 31u)); // base q in bits 1:0, q-1 in 3:2, ...
+        uint32_t mt = y ? (uint32_t)(__ffsll((unsigned long long)y) - 1) >> 1 : 32u;
+        if (mt > in) mt = in;
+        r += mt;
+        p -= mt;
+        if (mt < in) break;
+    }
+    return r > cap ? cap : r;
+}
+
+// counters: [0..3] terminal items per class, [4] items whose run hit the cap
+__global__ __launch_bounds__(CH_THREADS) void k_chain_runs(const uint64_t *__restrict__ pk, const uint32_t *srcP,
+                                                          int64_t beg, uint64_t N, int dir, uint32_t c, uint32_t cap,
+                                                          uint32_t termmask, uint32_t *__restrict__ run,
+                                                          uint64_t *__restrict__ tkey, uint32_t *__restrict__ tpos,
+                                                          uint32_t *__restrict__ counters)
+{
+    uint64_t i = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
+    uint32_t cls = 4u;
+    bool capped = false;
+    if (i < N) {
+        const uint64_t v = srcP[beg + (int64_t)dir * (int64_t)i];
+        const uint32_t r = run_before(pk, v, c, cap);
+        run[i] = r;
+        uint32_t u = 0;
+        if (r >= cap) capped = true;
+        else if (v - r >= 1) {
+            u = (uint32_t)(v - r - 1);
+            uint32_t x = kiss_base(pk, u);
+            if ((termmask >> x) & 1u) cls = x;
+        }
+        tkey[i] = cls < 4u ? (((uint64_t)cls << 62) | ((uint64_t)r << 46)) : ~0ull;
+        tpos[i] = u;
+    }
+#pragma unroll
+    for (uint32_t x = 0; x < 4; x++) {
+        uint64_t mk = __ballot(cls == x);
+        if (mk && lane_id() == 0) atomicAdd(&counters[x], (uint32_t)__popcll(mk));
+    }
+    uint64_t mk = __ballot(capped);
+    if (mk && lane_id() == 0) atomicAdd(&counters[4], (uint32_t)__popcll(mk));
+}
+
+__global__ void k_chain_total(const uint32_t *__restrict__ run, const uint32_t *__restrict__ ex, uint64_t N,
+                              uint32_t *__restrict__ counters)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) counters[5] = ex[N - 1] + run[N - 1];
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *srcP, int64_t beg, int dir, uint64_t N,
+                                                            const uint32_t *__restrict__ ex, uint64_t E,
+                                                            uint64_t *__restrict__ key, uint32_t *__restrict__ pos)
+{
+    uint64_t e = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
+    if (e >= E) return;
+    // last item i with ex[i] <= e
+    uint64_t lo = 0, hi = N;
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (ex[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t t = (uint32_t)(e - ex[lo]) + 1u;
+    key[e] = (uint64_t)t << 48;
+    pos[e] = srcP[beg + (int64_t)dir * (int64_t)lo] - t;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain_write(const uint64_t *__restrict__ pk,
+                                                           const uint32_t *__restrict__ sorted_pos, uint64_t E,
+                                                           int64_t dst, int dir, uint32_t *SA, uint32_t *CTX)
+{
+    uint64_t e = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint32_t u = sorted_pos[e];
+    const uint32_t cw = kiss_load_ctx(pk, u);
+    const int64_t d = dst + (int64_t)dir * (int64_t)e;
+    SA[d] = u;
+    CTX[d] = cw;
+}
+
+struct TermDst {
+    int64_t p[4];
+    uint32_t off[5];
+};
+
+__global__ __launch_bounds__(CH_THREADS) void k_chain_term_write(const uint64_t *__restrict__ pk,
+                                                                const uint32_t *__restrict__ sorted_tpos, uint64_t T,
+                                                                TermDst td, int dir, uint32_t *SA, uint32_t *CTX)
+{
+    uint64_t j = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
+    if (j >= T) return;
+    uint32_t x = 0;
+    while (x < 3 && j >= td.off[x + 1]) x++;
+    const uint32_t u = sorted_tpos[j];
+    const int64_t d = td.p[x] + (int64_t)dir * (int64_t)(j - td.off[x]);
+    SA[d] = u;
+    CTX[d] = kiss_load_ctx(pk, u);
+}
+
+int verify_part(kiss_hip_ctx *ctx, const uint32_t *SA, int64_t lo, int64_t hi, uint32_t c, uint64_t n, const char *what);
+int checksum_pk(kiss_hip_ctx *ctx, const char *what);
+
+// collapses the chain that starts with the N items at [beg, beg + dir*N) of SA (self class c)
+int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termmask)
+{
+    kiss_hip_ctx *ctx = sw.ctx;
+    uint32_t *run = ctx->slotA, *ex = ctx->segA, *tpos = ctx->bposA;
+    uint64_t *tkey = ctx->bkeyA;
+    uint32_t *counters = ctx->d_small + 16;
+    while (N > 0) {
+        uint64_t capq = ctx->m_cap / N;
+        uint32_t cap = (uint32_t)(capq > COLLAPSE_RCAP ? COLLAPSE_RCAP : (capq < 1 ? 1 : capq));
+        if (const char *e = getenv("KISS_HIP_COLLAPSE_CAP")) { // test hook: force short steps
+            uint32_t f = (uint32_t)atoi(e);
+            if (f >= 1 && f < cap) cap = f;
+        }
+        const unsigned grid = (unsigned)div_up(N, CH_THREADS);
+        ctx->stats.induce_passes++;
+        {
+            KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
+            KTRY(kiss_zero_u32(ctx, counters, 8));
+            hipLaunchKernelGGL(k_chain_runs, dim3(grid), dim3(CH_THREADS), 0, ctx->stream, ctx->pk, sw.SA, beg, N, sw.dir,
+                               c, cap, termmask & ~(1u << c), run, tkey, tpos, counters);
+            KCHECK(hipGetLastError());
+        }
+        KTRY(kiss_scan_u32(ctx, run, ex, N));
+        hipLaunchKernelGGL(k_chain_total, dim3(1), dim3(64), 0, ctx->stream, run, ex, N, counters);
+        KCHECK(hipMemcpyAsync(ctx->h_pinned, counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        uint32_t cnt[4];
+        for (int x = 0; x < 4; x++) cnt[x] = ctx->h_pinned[x];
+        const uint64_t ncap = ctx->h_pinned[4];
+        const uint64_t E = ctx->h_pinned[5];
+        if (getenv("KISS_HIP_DEBUG"))
+            fprintf(stderr, "[kiss_hip] collapse dir=%d c=%u beg=%lld N=%llu cap=%u E=%llu ncap=%llu term=%u,%u,%u,%u\n", sw.dir, c,
+                    (long long)beg, (unsigned long long)N, cap, (unsigned long long)E, (unsigned long long)ncap, cnt[0], cnt[1],
+                    cnt[2], cnt[3]);
+        if (E > ctx->m_cap) return KINTERNAL();
+        const int64_t dst = sw.pos[c];
+        if (E > 0) {
+            KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
+            hipLaunchKernelGGL(k_chain_expand, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
+                               sw.SA, beg, sw.dir, N, ex, E, ctx->keyA, ctx->posA);
+            KCHECK(hipGetLastError());
+        }
+        if (E > 0) {
+            RadixBufs rb;
+            rb.key[0] = ctx->keyA;
+            rb.key[1] = ctx->keyB;
+            rb.pos[0] = ctx->posA;
+            rb.pos[1] = ctx->posB;
+            rb.seg[0] = rb.seg[1] = nullptr;
+            int res = 0;
+            KTRY(kiss_radix_sort(ctx, rb, E, 48, 0, &res)); // step index t sits in bits 48..63
+            KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
+            hipLaunchKernelGGL(k_chain_write, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
+                               ctx->pk, rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
+            KCHECK(hipGetLastError());
+            if (getenv("KISS_HIP_VERIFY")) {
+                int64_t lo = sw.dir > 0 ? dst : dst - (int64_t)E + 1, hi = sw.dir > 0 ? dst + (int64_t)E : dst + 1;
+                KTRY(verify_part(ctx, sw.SA, lo, hi, c, ctx->n, "collapse block"));
+                KTRY(checksum_pk(ctx, "after collapse block"));
+            }
+        }
+        const uint64_t T = (uint64_t)cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (T > 0) {
+            RadixBufs tb;
+            tb.key[0] = ctx->bkeyA;
+            tb.key[1] = ctx->bkeyB;
+            tb.pos[0] = ctx->bposA;
+            tb.pos[1] = ctx->bposB;
+            tb.seg[0] = tb.seg[1] = nullptr;
+            int res = 0;
+            KTRY(kiss_radix_sort(ctx, tb, N, 46, 0, &res)); // (class, run) ; items without a terminal sort last
+            TermDst td;
+            uint32_t o = 0;
+            for (int x = 0; x < 4; x++) {
+                td.p[x] = sw.pos[x];
+                td.off[x] = o;
+                o += cnt[x];
+            }
+            td.off[4] = o;
+            KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, T);
+            hipLaunchKernelGGL(k_chain_term_write, dim3((unsigned)div_up(T, CH_THREADS)), dim3(CH_THREADS), 0,
+                               ctx->stream, ctx->pk, tb.pos[res], T, td, sw.dir, sw.SA, ctx->CTX);
+            KCHECK(hipGetLastError());
+        }
+        for (int x = 0; x < 4; x++) sw.pos[x] += (int64_t)sw.dir * (int64_t)cnt[x];
+        sw.pos[c] += (int64_t)sw.dir * (int64_t)E;
+        // items whose run reached the cap continue from the last block
+        beg = dst + (int64_t)sw.dir * (int64_t)(E - ncap);
+        N = ncap;
+    }
+    return KISS_HIP_OK;
+}
+
+__global__ void k_checksum(const uint64_t *__restrict__ pk, uint64_t words, unsigned long long *out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    for (; i < words; i += (uint64_t)gridDim.x * blockDim.x) v += pk[i] * (2 * i + 1);
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane_id() == 0) atomicAdd(out, v);
+}
+int checksum_pk(kiss_hip_ctx *ctx, const char *what)
+{
+    unsigned long long *d = (unsigned long long *)(ctx->d_small + 60);
+    KTRY(kiss_zero_u32(ctx, d, 2));
+    hipLaunchKernelGGL(k_checksum, dim3(256), dim3(256), 0, ctx->stream, ctx->pk, ctx->n / 32 + 2, d);
+    unsigned long long h = 0;
+    KCHECK(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[kiss_hip] pk checksum %016llx at %s\n", h, what);
+    return KISS_HIP_OK;
+}
+
+// debug: every SA entry of [lo, hi) must start with base c and carry a context word consistent with the text
+__global__ void k_verify_part(const uint64_t *__restrict__ pk, const uint32_t *SA, const uint32_t *CTX, int64_t lo,
+                              int64_t hi, uint32_t c, uint64_t n, uint32_t *bad)
+{
+    int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    uint32_t v = SA[i], cw = CTX[i];
+    bool ok = v < n && kiss_base(pk, v) == c;
+    if (ok && cw != KISS_EMPTY_CTX) {
+        uint32_t full = kiss_load_ctx(pk, v);
+        int mb = 31 - __clz(cw); // marker bit
+        uint32_t mask = (1u << mb) - 1u;
+        ok = (mb % 2 == 0) && mb <= 30 && ((full & mask) == (cw & mask)) && (31 - __clz(full)) >= mb;
+    }
+    if (!ok) {
+        uint32_t k = atomicAdd(&bad[0], 1u);
+        if (k < 6) {
+            bad[1 + 3 * k] = (uint32_t)i;
+            bad[2 + 3 * k] = v;
+            bad[3 + 3 * k] = cw;
+        }
+    }
+}
+
+int verify_part(kiss_hip_ctx *ctx, const uint32_t *SA, int64_t lo, int64_t hi, uint32_t c, uint64_t n, const char *what)
+{
+    if (hi <= lo) return KISS_HIP_OK;
+    uint32_t *bad = ctx->d_small + 40;
+    KTRY(kiss_zero_u32(ctx, bad, 20));
+    hipLaunchKernelGGL(k_verify_part, dim3((unsigned)div_up((uint64_t)(hi - lo), 256)), dim3(256), 0, ctx->stream, ctx->pk,
+                       SA, ctx->CTX, lo, hi, c, n, bad);
+    uint32_t h[20];
+    KCHECK(hipMemcpyAsync(h, bad, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[kiss_hip] verify %s c=%u [%lld,%lld): bad %u", what, c, (long long)lo, (long long)hi, h[0]);
+    for (uint32_t k = 0; k < h[0] && k < 6; k++) fprintf(stderr, " (idx %u v %u ctx %08x)", h[1 + 3 * k], h[2 + 3 * k], h[3 + 3 * k]);
+    fprintf(stderr, "\n");
     return KISS_HIP_OK;
 }
 
@@ -291,7 +575,7 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
         start[c + 1] = start[c] + cnt[c];
         lms_start[c + 1] = lms_start[c] + cntLMS[c];
     }
-    if (start[4] != n + 1) return KISS_HIP_E_INTERNAL;
+    if (start[4] != n + 1) return KINTERNAL();
 
     // SA[0] = n (the sentinel suffix); a one-item source {n} with an empty context word starts the L sweep
     uint32_t *seed = ctx->d_small + 32;
@@ -303,6 +587,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
 
     uint64_t tot[4];
     bool done;
+    if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "induce start"));
+    const uint64_t collapse_max = COLLAPSE_N < ctx->m_cap ? COLLAPSE_N : ctx->m_cap;
 
     // ---------------- L sweep: left to right ----------------
     Sweep L{ctx, d_SA, +1, {(int64_t)start[0], (int64_t)start[1], (int64_t)start[2], (int64_t)start[3]}};
@@ -312,16 +598,24 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
         const uint32_t mask_ge = (0xFu << c) & 0xFu; // L-type source of char c: v-1 is L-type iff S[v-1] >= c
         while (L.pos[c] > a) {
             uint64_t N = (uint64_t)(L.pos[c] - a);
+            if (N <= collapse_max) { // the rest of the chain in closed form
+                KTRY(run_collapse(L, (uint32_t)c, a, N, mask_ge));
+                a = L.pos[c];
+                break;
+            }
             KTRY(run_pass(L, d_SA, ctx->CTX, a, N, mask_ge, c, tot, &done));
             a = done ? L.pos[c] : a + (int64_t)N;
         }
-        if ((uint64_t)L.pos[c] != start[c] + cntL[c]) return KISS_HIP_E_INTERNAL;
+        if ((uint64_t)L.pos[c] != start[c] + cntL[c]) return KINTERNAL();
         if (cntLMS[c]) {
             const uint32_t mask_gt = (0xFu << (c + 1)) & 0xFu; // S[v-1] > c for every LMS suffix
             KTRY(run_pass(L, ctx->lmsP, ctx->lmsC, (int64_t)lms_start[c], cntLMS[c], mask_gt, -1, tot, &done));
         }
     }
 
+    if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "L sweep end"));
+    if (getenv("KISS_HIP_VERIFY"))
+        for (int c = 0; c < 4; c++) KTRY(verify_part(ctx, d_SA, (int64_t)start[c], (int64_t)(start[c] + cntL[c]), (uint32_t)c, n, "L-part"));
     // ---------------- S sweep: right to left ----------------
     Sweep S{ctx, d_SA, -1, {(int64_t)start[1] - 1, (int64_t)start[2] - 1, (int64_t)start[3] - 1, (int64_t)start[4] - 1}};
     for (int c = 3; c >= 0; c--) {
@@ -329,10 +623,19 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
         const uint32_t mask_le = (1u << (c + 1)) - 1u; // S-type source of char c: v-1 is S-type iff S[v-1] <= c
         while (S.pos[c] + 1 < hi) {
             uint64_t N = (uint64_t)(hi - (S.pos[c] + 1));
+            if (N <= collapse_max) {
+                KTRY(run_collapse(S, (uint32_t)c, hi - 1, N, mask_le));
+                hi = S.pos[c] + 1;
+                break;
+            }
             KTRY(run_pass(S, d_SA, ctx->CTX, hi - 1, N, mask_le, c, tot, &done));
             hi = done ? S.pos[c] + 1 : hi - (int64_t)N;
         }
-        if ((uint64_t)(S.pos[c] + 1) != start[c] + cntL[c]) return KISS_HIP_E_INTERNAL;
+        if ((uint64_t)(S.pos[c] + 1) != start[c] + cntL[c]) {
+            fprintf(stderr, "[kiss_hip] S sweep bucket %d: tail %lld, expected %llu\n", c, (long long)(S.pos[c] + 1),
+                    (unsigned long long)(start[c] + cntL[c]));
+            return KINTERNAL();
+        }
         if (cntL[c] && c > 0) {
             const uint32_t mask_lt = (1u << c) - 1u; // L-type source of char c: v-1 is S-type iff S[v-1] < c
             KTRY(run_pass(S, d_SA, ctx->CTX, (int64_t)(start[c] + cntL[c]) - 1, cntL[c], mask_lt, -1, tot, &done));

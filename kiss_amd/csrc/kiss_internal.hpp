@@ -26,6 +26,10 @@ struct kiss_hip_ctx;
         if (s__ != KISS_HIP_OK) return s__; \
     } while (0)
 
+// an internal invariant failed: say where (this is a bug report, not a user error)
+#include <cstdio>
+#define KINTERNAL() (fprintf(stderr, "[kiss_hip] internal check failed at %s:%d\n", __FILE__, __LINE__), KISS_HIP_E_INTERNAL)
+
 // ---- device workspace -----------------------------------------------------------
 struct kiss_hip_ctx {
     int device = 0;
@@ -103,6 +107,8 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*
 // exclusive scans (in place allowed: out may equal in)
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count);
 int kiss_scan_u64(kiss_hip_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t count);
+// zero count_u32 32-bit words at p with a kernel on the ctx stream
+int kiss_zero_u32(kiss_hip_ctx *ctx, void *p, uint64_t count_u32);
 // stable LSD radix sort of (key64[, seg32], pos32) tuples; bits [key_lo_bit,64) of key then seg_bits of seg.
 // Buffers ping-pong; on return *in_is_result tells which pair holds the sorted data (true = the A buffers).
 struct RadixBufs {
@@ -127,7 +133,7 @@ __device__ __forceinline__ uint64_t kiss_key32(const uint64_t *__restrict__ pk, 
     uint32_t s = (uint32_t)(p & 31u) * 2u;
     uint64_t a = pk[w];
     uint64_t b = pk[w + 1];
-    return s ? ((a << s) | (b >> (64u - s))) : a;
+    return (a << s) | ((b >> 1) >> (63u - s)); // branch-free: s == 0 gives a
 }
 __device__ __forceinline__ uint32_t kiss_base(const uint64_t *__restrict__ pk, uint64_t p)
 {

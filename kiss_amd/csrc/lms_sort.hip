@@ -265,7 +265,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     // ------------------------------ rounds >= 1 ---------------------------------------------
     uint64_t off = ROUND0_BASES;
     while (count > 0) {
-        if (depth && off >= depth) return KISS_HIP_E_INTERNAL; // the last round retires everything
+        if (depth && off >= depth) return KINTERNAL(); // the last round retires everything
         uint64_t rem = depth ? depth - off : 32;
         if (rem > 32) rem = 32;
         const bool last_round = depth ? (off + 32 >= depth) : false;
@@ -306,7 +306,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         }
         uint64_t bt;
         KTRY(read_u64(ctx, d_total, &bt));
-        if ((bt >> 32) != nbig) return KISS_HIP_E_INTERNAL;
+        if ((bt >> 32) != nbig) return KINTERNAL();
         const uint64_t nbigseg = bt & 0xFFFFFFFFull;
         RadixBufs bb;
         bb.key[0] = ctx->bkeyA;
@@ -337,7 +337,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         count = tot >> 32;
         nseg = tot & 0xFFFFFFFFull;
         off += 32;
-        if (!depth && off > n + 64 && count > 0) return KISS_HIP_E_INTERNAL; // exact mode must have terminated
+        if (!depth && off > n + 64 && count > 0) return KINTERNAL(); // exact mode must have terminated
     }
     return KISS_HIP_OK;
 }

@@ -212,7 +212,7 @@ int radix_offsets(kiss_hip_ctx *ctx, uint64_t tiles)
 {
     const uint64_t chunks = div_up(tiles, RX_CHUNK);
     uint32_t *csum = ctx->tile_hist + 256 * tiles; // room reserved behind the matrix
-    if (256 * tiles + 256 * chunks > ctx->tile_hist_cap) return KISS_HIP_E_INTERNAL;
+    if (256 * tiles + 256 * chunks > ctx->tile_hist_cap) return KINTERNAL();
     {
         KTimer t(ctx, KISS_HIP_K_SCAN, 256 * tiles);
         hipLaunchKernelGGL(k_col_sum, dim3((unsigned)chunks), dim3(256), 0, ctx->stream, ctx->tile_hist, tiles, chunks,

@@ -160,7 +160,7 @@ int scan_impl(kiss_hip_ctx *ctx, const T *in, T *out, uint64_t count)
 {
     if (count == 0) return KISS_HIP_OK;
     const uint64_t nb = div_up(count, SCAN_BLOCK);
-    if (nb > ctx->scan_tmp_cap) return KISS_HIP_E_INTERNAL;
+    if (nb > ctx->scan_tmp_cap) return KINTERNAL();
     T *bs = reinterpret_cast<T *>(ctx->scan_tmp);
     KTimer t(ctx, KISS_HIP_K_SCAN, count);
     hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, count, bs);
@@ -171,6 +171,22 @@ int scan_impl(kiss_hip_ctx *ctx, const T *in, T *out, uint64_t count)
 }
 
 } // namespace
+
+// zero-fill as an ordinary kernel on the ctx stream (keeps strict kernel-after-kernel ordering; used instead of
+// hipMemsetAsync between dependent kernels)
+__global__ void k_zero_u32(uint32_t *p, uint64_t count)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = 0;
+}
+int kiss_zero_u32(kiss_hip_ctx *ctx, void *p, uint64_t count_u32)
+{
+    if (!count_u32) return KISS_HIP_OK;
+    hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)div_up(count_u32, 256)), dim3(256), 0, ctx->stream, (uint32_t *)p,
+                       count_u32);
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}
 
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count)
 {
