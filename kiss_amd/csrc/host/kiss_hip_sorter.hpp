@@ -1,0 +1,76 @@
+// kiss_hip_sorter.hpp -- header-only C++ host facade over the C ABI (include/kiss_hip.h).
+//
+// `biovoltron::KissHipSorter<uint32_t>` has the shape of the reference's sorter facades
+// (reference include/biovoltron/algo/sort/kiss1_sorter.hpp:8-50, kiss2_sorter.hpp:8-50) and satisfies the
+// `SASorter` concept (algo/sort/sorter.hpp:7-10): static `get_suffix_array_dna(S, k, num_threads)` returning an
+// SA of n+1 entries, the range overload, and `prepare_aligned_ref`.  It can therefore be the `Sorter` template
+// argument of `FMIndex<SA_INTV, size_type, Sorter>` (algo/align/exact_match/fm_index.hpp:384-387) and an
+// alternative of the std::variant in `suffix_sort_main` (include/command/suffix_sort.hpp:37-60).
+// Errors become exceptions here, like the reference's own error style (std::invalid_argument / bad_alloc);
+// nothing C++ crosses the ABI itself.  `num_threads` is accepted and ignored (no result depends on it).
+#pragma once
+#include <cstdint>
+#include <new>
+#include <ranges>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/kiss_hip.h"
+
+namespace biovoltron {
+
+template <typename size_type = std::uint32_t>
+struct KissHipSorter {
+  static_assert(sizeof(size_type) == 4, "the HIP path implements the CLI's uint32_t index type (suffix_sort.hpp:37)");
+  using SA_t = std::vector<size_type>;
+
+  static int& device() {
+    static int d = 0;
+    return d;
+  }
+
+  static void check(int rc, const char* where) {
+    if (rc == KISS_HIP_OK) return;
+    if (rc == KISS_HIP_E_NOMEM) throw std::bad_alloc{};
+    throw std::runtime_error(std::string(where) + ": " + kiss_hip_strerror(rc));
+  }
+
+  // kiss1_sorter.hpp:46-49 (the reference copies into a 64-byte aligned vector; the ABI has no alignment need)
+  static auto prepare_aligned_ref(const std::ranges::random_access_range auto& ref) {
+    std::vector<std::uint8_t> S(std::ranges::size(ref));
+    std::size_t i = 0;
+    for (auto c : ref) S[i++] = static_cast<std::uint8_t>(c);
+    return S;
+  }
+
+  // kiss1_sorter.hpp:20-26
+  static SA_t get_suffix_array_dna(const std::vector<std::uint8_t>& S, size_type k = 256u,
+                                   std::size_t /*num_threads*/ = std::thread::hardware_concurrency(),
+                                   int algo = KISS_HIP_ALGO_PARALLEL_SORTING) {
+    SA_t SA(S.size() + 1);
+    check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k, algo, reinterpret_cast<std::uint32_t*>(SA.data()),
+                                       device()),
+          "kiss_hip_suffix_sort_dna_u32");
+    return SA;
+  }
+
+  // range overload, kiss1_sorter.hpp:28-34
+  static SA_t get_suffix_array_dna(const std::ranges::random_access_range auto& ref, size_type k = 256u,
+                                   std::size_t num_threads = std::thread::hardware_concurrency()) {
+    return get_suffix_array_dna(prepare_aligned_ref(ref), k, num_threads);
+  }
+};
+
+// KISS2 (PREFIX_DOUBLING): defined for k >= n only (exact suffix array), see DESIGN.md section 8
+template <typename size_type = std::uint32_t>
+struct KissHipSorter2 : KissHipSorter<size_type> {
+  using SA_t = typename KissHipSorter<size_type>::SA_t;
+  static SA_t get_suffix_array_dna(const std::vector<std::uint8_t>& S, size_type k = 0xFFFFFFFFu,
+                                   std::size_t t = std::thread::hardware_concurrency()) {
+    return KissHipSorter<size_type>::get_suffix_array_dna(S, k, t, KISS_HIP_ALGO_PREFIX_DOUBLING);
+  }
+};
+
+}  // namespace biovoltron

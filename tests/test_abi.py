@@ -51,3 +51,13 @@ def test_stats_struct_matches_header():
     # sizeof(kiss_hip_stats) computed from the header's field list
     assert ctypes.sizeof(_lib.Stats) == 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 6 * 4 + 16 * 4 + 4 + 16 * 8 + 16 * 8 or \
         ctypes.sizeof(_lib.Stats) % 8 == 0
+
+
+def test_cpp_host_facade_compiles_and_links(tmp_path):
+    # the header-only C++ facade satisfies the reference's SASorter shape and links against the library
+    import subprocess
+    exe = tmp_path / "hfc"
+    cmd = ["g++", "-std=c++20", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "host_facade_check.cpp"), "-o",
+           str(exe), "-L" + os.path.join(ROOT, "kiss_amd"), "-lkiss_hip", "-Wl,-rpath," + os.path.join(ROOT, "kiss_amd")]
+    subprocess.check_call(cmd)
+    assert subprocess.call([str(exe)]) == 0
