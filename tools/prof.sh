@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools_prof.sh <tag> <bench args...>   (runs on the GPU box; writes gpurun_out/<tag>_kernel_stats.csv)
 tag=$1; shift
-root=${GRAFT_REPO_ROOT:-$(pwd)}
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $root/gpurun_out /tmp/prof_$tag
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $root/bench.py "$@" > $root/gpurun_out/${tag}_bench.json 2> $root/gpurun_out/${tag}_err.log
