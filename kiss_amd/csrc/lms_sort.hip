@@ -70,15 +70,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           const uint32_t *__restrict__ slot,
                                                           const uint32_t *__restrict__ seg,
                                                           const uint32_t *__restrict__ segstart, uint64_t count,
-                                                          uint64_t off, uint64_t depth, uint32_t *__restrict__ out,
-                                                          uint64_t *__restrict__ big, uint32_t *__restrict__ nbig)
+                                                          uint64_t off, uint64_t depth, uint32_t small_seg,
+                                                          uint32_t *__restrict__ out, uint64_t *__restrict__ big,
+                                                          uint32_t *__restrict__ nbig)
 {
     uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     bool isbig = false;
     if (i < count) {
         uint32_t sg = seg[i];
         uint32_t a = segstart[sg], b = segstart[sg + 1];
-        if (b - a <= SMALL_SEG) {
+        if (b - a <= small_seg) {
             const uint64_t ki = key[i];
             const uint64_t pi = pos[i];
             uint32_t r = 0;
@@ -221,6 +222,11 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    uint32_t small_seg = SMALL_SEG;
+    if (const char *e = getenv("KISS_HIP_SMALL_SEG")) { // tuning hook
+        int v = atoi(e);
+        if (v >= 2 && v <= 4096) small_seg = (uint32_t)v;
+    }
 
     // ------------------------------ round 0 ------------------------------------------------
     uint64_t count = m_far;
@@ -282,7 +288,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, d_nbig);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
-                               count, off, depth, ctx->lms_sorted_far, F1, d_nbig);
+                               count, off, depth, small_seg, ctx->lms_sorted_far, F1, d_nbig);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;

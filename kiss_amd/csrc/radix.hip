@@ -46,21 +46,24 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
     (void)tiles;
 }
 
+// Scatter.  LDS holds ONE 32 KiB staging buffer that the key, position and segment columns pass through in
+// turn (each column is reordered locally and leaves as coalesced per-digit runs), so four workgroups fit a CU.
 template <int SRC, bool HAS_SEG>
-__global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__restrict__ key_in,
-                                                             const uint32_t *__restrict__ seg_in,
-                                                             const uint32_t *__restrict__ pos_in,
-                                                             uint64_t *__restrict__ key_out,
-                                                             uint32_t *__restrict__ seg_out,
-                                                             uint32_t *__restrict__ pos_out, uint64_t count, int shift,
-                                                             const uint32_t *__restrict__ tile_off, uint64_t tiles)
+__global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ key_in,
+                                                                const uint32_t *__restrict__ seg_in,
+                                                                const uint32_t *__restrict__ pos_in,
+                                                                uint64_t *__restrict__ key_out,
+                                                                uint32_t *__restrict__ seg_out,
+                                                                uint32_t *__restrict__ pos_out, uint64_t count,
+                                                                int shift, const uint32_t *__restrict__ tile_off,
+                                                                uint64_t tiles)
 {
-    __shared__ uint64_t skey[RX_TILE];
-    __shared__ uint32_t spos[RX_TILE];
-    __shared__ uint32_t sseg[HAS_SEG ? RX_TILE : 1];
+    __shared__ uint64_t stage64[RX_TILE];
     __shared__ uint32_t wcnt[RX_WAVES][256];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t wsum[RX_WAVES + 1];
+    uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage64);
+    (void)tiles;
 
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
@@ -85,6 +88,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__
         k[j] = valid ? key_in[g] : 0ull;
         s[j] = (HAS_SEG && valid) ? seg_in[g] : 0u;
         p[j] = valid ? pos_in[g] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const uint32_t li = wbase + (uint32_t)j * 64;
+        const bool valid = li < tile_count;
         const uint32_t d = digit_of<SRC>(k[j], s[j], shift);
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -125,7 +133,6 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__
         uint32_t start = inc - tot;
         for (int w = 0; w < wave; w++) start += wsum[w];
         gbase[d] = tile_off[(uint64_t)blockIdx.x * 256 + d] - start;
-        (void)tiles;
         uint32_t run = start;
 #pragma unroll
         for (int w = 0; w < RX_WAVES; w++) {
@@ -135,27 +142,77 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_scatter(const uint64_t *__
     }
     __syncthreads();
 
-    // local reorder through LDS
+    // local positions of this thread's items
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        if (rk[j] != 0xFFFFFFFFu) {
-            const uint32_t d = rk[j] >> 16;
-            const uint32_t lp = wcnt[wave][d] + (rk[j] & 0xFFFFu);
-            skey[lp] = k[j];
-            spos[lp] = p[j];
-            if (HAS_SEG) sseg[lp] = s[j];
-        }
-    }
-    __syncthreads();
+    for (int j = 0; j < RX_ITEMS; j++)
+        if (rk[j] != 0xFFFFFFFFu) rk[j] = wcnt[wave][rk[j] >> 16] + (rk[j] & 0xFFFFu);
 
-    for (uint32_t idx = threadIdx.x; idx < tile_count; idx += RX_THREADS) {
-        const uint64_t kk = skey[idx];
-        const uint32_t ss = HAS_SEG ? sseg[idx] : 0u;
-        const uint32_t d = digit_of<SRC>(kk, ss, shift);
-        const uint32_t o = gbase[d] + idx;
-        key_out[o] = kk;
-        pos_out[o] = spos[idx];
-        if (HAS_SEG) seg_out[o] = ss;
+    // global offsets of the output slots this thread will write: slot idx = threadIdx.x + 256 * r
+    uint32_t gofs[RX_ITEMS];
+
+    // ---- the column that carries the digit goes first (key for SRC == 0, segment for SRC == 1)
+    if (SRC == 0) {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++)
+            if (rk[j] != 0xFFFFFFFFu) stage64[rk[j]] = k[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RX_ITEMS; r++) {
+            const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
+            if (idx < tile_count) {
+                const uint64_t kk = stage64[idx];
+                gofs[r] = gbase[(uint32_t)(kk >> shift) & 255u] + idx;
+                key_out[gofs[r]] = kk;
+            }
+        }
+        __syncthreads();
+        if (HAS_SEG) {
+#pragma unroll
+            for (int j = 0; j < RX_ITEMS; j++)
+                if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = s[j];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RX_ITEMS; r++) {
+                const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
+                if (idx < tile_count) seg_out[gofs[r]] = stage32[idx];
+            }
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++)
+            if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = s[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RX_ITEMS; r++) {
+            const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
+            if (idx < tile_count) {
+                const uint32_t ss = stage32[idx];
+                gofs[r] = gbase[(ss >> shift) & 255u] + idx;
+                seg_out[gofs[r]] = ss;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++)
+            if (rk[j] != 0xFFFFFFFFu) stage64[rk[j]] = k[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RX_ITEMS; r++) {
+            const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
+            if (idx < tile_count) key_out[gofs[r]] = stage64[idx];
+        }
+        __syncthreads();
+    }
+    // ---- positions
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++)
+        if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = p[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RX_ITEMS; r++) {
+        const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
+        if (idx < tile_count) pos_out[gofs[r]] = stage32[idx];
     }
 }
 
