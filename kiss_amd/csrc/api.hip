@@ -159,7 +159,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
     free_lms_side(ctx);
     const uint64_t before = ctx->ws_bytes;
     ctx->m_cap = m_cap;
-    const uint64_t radix_tiles = m_cap / 4096 + 2;
+    const uint64_t radix_tiles = m_cap / 2048 + 2; // sized for the smallest radix tile in use
     ctx->tile_hist_cap = 256 * radix_tiles + 256 * (radix_tiles / 64 + 2) + 8;
     uint64_t biggest_scan = m_cap;
     if (ctx->tile_hist_cap > biggest_scan) biggest_scan = ctx->tile_hist_cap;

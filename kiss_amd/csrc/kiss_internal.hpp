@@ -150,6 +150,12 @@ __device__ __forceinline__ uint32_t kiss_load_ctx(const uint64_t *__restrict__ p
     uint64_t w0 = pk[0];
     return (uint32_t)(w0 >> (64u - 2u * (uint32_t)v)) | (1u << (2u * (uint32_t)v));
 }
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's
+// outstanding global stores (vmcnt), so a store burst overlaps the next LDS staging step
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt()
 {

@@ -12,11 +12,11 @@
 
 namespace {
 
-constexpr int RX_THREADS = 256;
+constexpr int RX_THREADS = 1024;
 constexpr int RX_ITEMS = 16;
 constexpr int RX_WAVES = RX_THREADS / 64;
 constexpr int RX_WAVE_TILE = RX_ITEMS * 64;        // 1024
-constexpr int RX_TILE = RX_THREADS * RX_ITEMS;     // 4096
+constexpr int RX_TILE = RX_THREADS * RX_ITEMS;     // 8192
 
 template <int SRC>
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, uint32_t seg, int shift)
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
                                                           uint32_t *__restrict__ tile_hist, uint64_t tiles)
 {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * RX_TILE + (uint64_t)(threadIdx.x >> 6) * RX_WAVE_TILE + lane_id();
 #pragma unroll
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
         }
     }
     __syncthreads();
-    tile_hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x]; // tile-major: one coalesced 1 KiB row
+    if (threadIdx.x < 256) tile_hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x]; // tile-major row
     (void)tiles;
 }
 
@@ -70,8 +70,10 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
     const uint32_t tile_count = (uint32_t)((count - tile_base) < (uint64_t)RX_TILE ? (count - tile_base) : RX_TILE);
 
+    if (threadIdx.x < 256) {
 #pragma unroll
-    for (int w = 0; w < RX_WAVES; w++) wcnt[w][threadIdx.x] = 0;
+        for (int w = 0; w < RX_WAVES; w++) wcnt[w][threadIdx.x] = 0;
+    }
     __syncthreads();
 
     uint64_t k[RX_ITEMS];
@@ -94,13 +96,17 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
         const uint32_t li = wbase + (uint32_t)j * 64;
         const bool valid = li < tile_count;
         const uint32_t d = digit_of<SRC>(k[j], s[j], shift);
-        uint64_t peers = __ballot(valid);
+        // lanes holding the same digit: AND over the 8 digit bits of (bit ? ballot : ~ballot) = ~(ballot ^ -bit)
+        const uint64_t vm = __ballot(valid);
+        uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bm = __ballot(bit);
-            peers &= bit ? bm : ~bm;
+            const uint32_t sel = 0u - ((d >> b) & 1u);
+            const uint64_t bm = __ballot(sel != 0u);
+            plo &= ~((uint32_t)bm ^ sel);
+            phi &= ~((uint32_t)(bm >> 32) ^ sel);
         }
+        const uint64_t peers = ((uint64_t)phi << 32) | plo;
         uint32_t old = 0;
         int leader = 0;
         if (valid) {
@@ -112,14 +118,15 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     }
     __syncthreads();
 
-    // per digit: totals over waves, exclusive prefix over waves, exclusive scan over digits
+    // per digit (threads 0..255): totals over waves, exclusive prefix over waves, exclusive scan over digits
     {
-        const uint32_t d = threadIdx.x;
+        const uint32_t d = threadIdx.x & 255u;
+        const bool dig = threadIdx.x < 256;
         uint32_t c[RX_WAVES];
         uint32_t tot = 0;
 #pragma unroll
         for (int w = 0; w < RX_WAVES; w++) {
-            c[w] = wcnt[w][d];
+            c[w] = dig ? wcnt[w][d] : 0u;
             tot += c[w];
         }
         uint32_t inc = tot;
@@ -128,16 +135,18 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
             uint32_t o = __shfl_up(inc, dd, 64);
             if ((int)lane >= dd) inc += o;
         }
-        if (lane == 63) wsum[wave] = inc;
+        if (lane == 63 && dig) wsum[wave] = inc;
         __syncthreads();
-        uint32_t start = inc - tot;
-        for (int w = 0; w < wave; w++) start += wsum[w];
-        gbase[d] = tile_off[(uint64_t)blockIdx.x * 256 + d] - start;
-        uint32_t run = start;
+        if (dig) {
+            uint32_t start = inc - tot;
+            for (int w = 0; w < wave; w++) start += wsum[w];
+            gbase[d] = tile_off[(uint64_t)blockIdx.x * 256 + d] - start;
+            uint32_t run = start;
 #pragma unroll
-        for (int w = 0; w < RX_WAVES; w++) {
-            wcnt[w][d] = run;
-            run += c[w];
+            for (int w = 0; w < RX_WAVES; w++) {
+                wcnt[w][d] = run;
+                run += c[w];
+            }
         }
     }
     __syncthreads();
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++)
             if (rk[j] != 0xFFFFFFFFu) stage64[rk[j]] = k[j];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < RX_ITEMS; r++) {
             const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
@@ -165,24 +174,24 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
                 key_out[gofs[r]] = kk;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (HAS_SEG) {
 #pragma unroll
             for (int j = 0; j < RX_ITEMS; j++)
                 if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = s[j];
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < RX_ITEMS; r++) {
                 const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
                 if (idx < tile_count) seg_out[gofs[r]] = stage32[idx];
             }
-            __syncthreads();
+            lds_barrier();
         }
     } else {
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++)
             if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = s[j];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < RX_ITEMS; r++) {
             const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
@@ -192,23 +201,23 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
                 seg_out[gofs[r]] = ss;
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++)
             if (rk[j] != 0xFFFFFFFFu) stage64[rk[j]] = k[j];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int r = 0; r < RX_ITEMS; r++) {
             const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
             if (idx < tile_count) key_out[gofs[r]] = stage64[idx];
         }
-        __syncthreads();
+        lds_barrier();
     }
     // ---- positions
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++)
         if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = p[j];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < RX_ITEMS; r++) {
         const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;

@@ -4,7 +4,7 @@ tag=$1; shift; ctrs=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $root/gpurun_out /tmp/pmc_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -- python3 $root/bench.py "$@" > $root/gpurun_out/${tag}_bench.json 2> $root/gpurun_out/${tag}_err.log
+rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -- python3 $root/tools/pmc_driver.py "$@" > $root/gpurun_out/${tag}_bench.json 2> $root/gpurun_out/${tag}_err.log
 f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
 cd $root
 python3 - "$f" "$tag" <<'PY'
