@@ -167,6 +167,151 @@ __global__ __launch_bounds__(LS_THREADS) void k_compact(const uint32_t *__restri
     }
 }
 
+// ---- fused flag + compaction over 2048-item tiles (no per-item flag / scan arrays) ------------------------
+// pass 1: per-tile (survivors << 32 | surviving heads); pass 2 (after an exclusive scan over tiles): the same
+// flags again, wave-ballot prefix inside the tile, survivors compacted, singletons retired.
+constexpr int FC_THREADS = 256;
+constexpr int FC_ITEMS = 8;
+constexpr int FC_TILE = FC_THREADS * FC_ITEMS;
+
+template <bool HAS_SEG>
+__device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const uint32_t *__restrict__ seg, uint64_t i,
+                                         uint64_t count, int cmp_shift, int last_round, bool &surv, bool &shead)
+{
+    surv = shead = false;
+    if (i >= count) return;
+    uint64_t k = key[i] >> cmp_shift;
+    uint32_t s = HAS_SEG ? seg[i] : 0u;
+    bool head = (i == 0) || (key[i - 1] >> cmp_shift) != k || (HAS_SEG && seg[i - 1] != s);
+    bool nhead = (i + 1 == count) || (key[i + 1] >> cmp_shift) != k || (HAS_SEG && seg[i + 1] != s);
+    surv = !(head && nhead) && !last_round;
+    shead = surv && head;
+}
+
+template <bool HAS_SEG>
+__global__ __launch_bounds__(FC_THREADS) void k_fc_count(const uint64_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ seg, uint64_t count,
+                                                        int cmp_shift, int last_round, uint64_t *__restrict__ tcnt)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * FC_TILE + (uint64_t)wave * (FC_ITEMS * 64) + lane_id();
+    uint32_t ns = 0, nh = 0;
+#pragma unroll
+    for (int j = 0; j < FC_ITEMS; j++) {
+        bool sv, sh;
+        fc_flags<HAS_SEG>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
+        ns += (uint32_t)__popcll(__ballot(sv));
+        nh += (uint32_t)__popcll(__ballot(sh));
+    }
+    if (lane_id() == 0) {
+        ws[wave][0] = ns;
+        ws[wave][1] = nh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t a = 0, b = 0;
+        for (int w = 0; w < FC_THREADS / 64; w++) {
+            a += ws[w][0];
+            b += ws[w][1];
+        }
+        tcnt[blockIdx.x] = (a << 32) | b;
+    }
+}
+
+template <bool HAS_SEG, bool HAS_SLOT>
+__global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__restrict__ key,
+                                                          const uint32_t *__restrict__ seg,
+                                                          const uint32_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ slot, uint64_t count,
+                                                          int cmp_shift, int last_round,
+                                                          const uint64_t *__restrict__ tex, // exclusive scan of tcnt
+                                                          uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
+                                                          uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
+                                                          uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * FC_TILE + (uint64_t)wave * (FC_ITEMS * 64) + lane_id();
+    uint32_t rs[FC_ITEMS], rh[FC_ITEMS]; // rank among survivors / surviving heads inside the wave (inclusive for heads)
+    uint32_t fl = 0;                      // bit 2j = survivor, bit 2j+1 = surviving head
+    uint32_t ns = 0, nh = 0;
+#pragma unroll
+    for (int j = 0; j < FC_ITEMS; j++) {
+        bool sv, sh;
+        fc_flags<HAS_SEG>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
+        const uint64_t ms = __ballot(sv), mh = __ballot(sh);
+        rs[j] = ns + (uint32_t)__popcll(ms & lanemask_lt());
+        rh[j] = nh + (uint32_t)__popcll(mh & lanemask_lt()) + (sh ? 1u : 0u);
+        ns += (uint32_t)__popcll(ms);
+        nh += (uint32_t)__popcll(mh);
+        fl |= (sv ? 1u : 0u) << (2 * j) | (sh ? 2u : 0u) << (2 * j);
+    }
+    if (lane_id() == 0) {
+        ws[wave][0] = ns;
+        ws[wave][1] = nh;
+    }
+    __syncthreads();
+    const uint64_t te = tex[blockIdx.x];
+    uint32_t bs = (uint32_t)(te >> 32), bh = (uint32_t)(te & 0xFFFFFFFFull);
+    for (int w = 0; w < wave; w++) {
+        bs += ws[w][0];
+        bh += ws[w][1];
+    }
+#pragma unroll
+    for (int j = 0; j < FC_ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * 64;
+        if (i >= count) continue;
+        const uint32_t p = pos[i];
+        const uint32_t sl = HAS_SLOT ? slot[i] : (uint32_t)i;
+        if ((fl >> (2 * j)) & 1u) {
+            const uint32_t ni = bs + rs[j];
+            const uint32_t sid = bh + rh[j] - 1u; // heads up to and including this item's own segment head
+            npos[ni] = p;
+            nslot[ni] = sl;
+            nseg[ni] = sid;
+            if ((fl >> (2 * j)) & 2u) nsegstart[sid] = ni;
+        } else {
+            out[sl] = p;
+        }
+    }
+}
+
+__global__ void k_fc_total(const uint64_t *__restrict__ tcnt, const uint64_t *__restrict__ tex, uint64_t tiles,
+                           uint64_t *__restrict__ total)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = tex[tiles - 1] + tcnt[tiles - 1];
+}
+
+// flag + compact of `count` sorted items; on return *tot = (survivors << 32) | surviving segments
+template <bool HAS_SEG, bool HAS_SLOT>
+int fused_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
+                  uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
+                  uint32_t *nsegstart, uint64_t *d_total, uint64_t *tot)
+{
+    const uint64_t tiles = div_up(count, FC_TILE);
+    uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles; // 2 * tiles u64 << 2 * m_cap
+    {
+        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+        hipLaunchKernelGGL((k_fc_count<HAS_SEG>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
+                           cmp_shift, last_round, tcnt);
+        KCHECK(hipGetLastError());
+    }
+    KTRY(kiss_scan_u64(ctx, tcnt, tex, tiles));
+    {
+        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+        hipLaunchKernelGGL((k_fc_compact<HAS_SEG, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key,
+                           seg, pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
+                           ctx->lms_sorted_far);
+        hipLaunchKernelGGL(k_fc_total, dim3(1), dim3(64), 0, ctx->stream, tcnt, tex, tiles, d_total);
+        KCHECK(hipGetLastError());
+    }
+    KCHECK(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(tot, ctx->h_pinned, sizeof(uint64_t));
+    return KISS_HIP_OK;
+}
+
 __global__ void k_last_total(const uint64_t *__restrict__ flags, const uint64_t *__restrict__ ex, uint64_t count,
                              uint64_t *__restrict__ total)
 {
@@ -245,22 +390,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     ctx->stats.sort_item_rounds += count;
     uint32_t *Pc = rb.pos[res ^ 1]; // receives the survivors' positions
     uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
-    {
-        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_flag<false>), dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, rb.key[res],
-                           (const uint32_t *)nullptr, count, r0_shift, 0, F1);
-        KCHECK(hipGetLastError());
-    }
-    KTRY(kiss_scan_u64(ctx, F1, F2, count));
-    {
-        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_compact<false>), dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, rb.pos[res],
-                           (const uint32_t *)nullptr, count, F1, F2, Pc, Sc, Gc, SSc, ctx->lms_sorted_far);
-        hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
-        KCHECK(hipGetLastError());
-    }
     uint64_t tot;
-    KTRY(read_u64(ctx, d_total, &tot));
+    KTRY((fused_compact<false, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
+                                     d_total, &tot)));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     if (dbg)
@@ -324,22 +456,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         int bres = 0;
         KTRY(kiss_radix_sort(ctx, bb, nbig, key_lo_bit, bits_for(nbigseg), &bres));
         ctx->stats.big_item_rounds += nbig;
-        const unsigned bgrid = (unsigned)div_up(nbig, T);
-        {
-            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
-            hipLaunchKernelGGL((k_flag<true>), dim3(bgrid), dim3(T), 0, ctx->stream, bb.key[bres], bb.seg[bres], nbig, 0,
-                               (int)last_round, F1);
-            KCHECK(hipGetLastError());
-        }
-        KTRY(kiss_scan_u64(ctx, F1, F2, nbig));
-        {
-            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
-            hipLaunchKernelGGL((k_compact<true>), dim3(bgrid), dim3(T), 0, ctx->stream, bb.pos[bres], ctx->bslot, nbig,
-                               F1, F2, Pc, Sc, Gc, SSc, ctx->lms_sorted_far);
-            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, nbig, d_total);
-            KCHECK(hipGetLastError());
-        }
-        KTRY(read_u64(ctx, d_total, &tot));
+        KTRY((fused_compact<true, true>(ctx, bb.key[bres], bb.seg[bres], bb.pos[bres], ctx->bslot, nbig, 0, (int)last_round,
+                                       Pc, Sc, Gc, SSc, d_total, &tot)));
         count = tot >> 32;
         nseg = tot & 0xFFFFFFFFull;
         off += 32;
