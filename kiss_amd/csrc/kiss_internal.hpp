@@ -131,8 +131,9 @@ __device__ __forceinline__ uint64_t kiss_key32(const uint64_t *__restrict__ pk, 
 {
     uint64_t w = p >> 5;
     uint32_t s = (uint32_t)(p & 31u) * 2u;
-    uint64_t a = pk[w];
-    uint64_t b = pk[w + 1];
+    // one 16-byte load for both words (global loads only need dword alignment on gfx950)
+    const ulonglong2 ab = *reinterpret_cast<const ulonglong2 *>(pk + w);
+    const uint64_t a = ab.x, b = ab.y;
     return (a << s) | ((b >> 1) >> (63u - s)); // branch-free: s == 0 gives a
 }
 __device__ __forceinline__ uint32_t kiss_base(const uint64_t *__restrict__ pk, uint64_t p)

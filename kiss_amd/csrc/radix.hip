@@ -29,21 +29,58 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
                                                           const uint32_t *__restrict__ seg, uint64_t count, int shift,
                                                           uint32_t *__restrict__ tile_hist, uint64_t tiles)
 {
-    __shared__ uint32_t h[256];
-    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    // one private 256-bin histogram per wave (LDS atomics only collide inside a wave), summed at the end
+    __shared__ uint32_t h[RX_WAVES][256];
+    (void)tiles;
+    const int wave = threadIdx.x >> 6;
+    for (uint32_t i = threadIdx.x; i < RX_WAVES * 256; i += RX_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * RX_TILE + (uint64_t)(threadIdx.x >> 6) * RX_WAVE_TILE + lane_id();
+    const uint64_t wbase = (uint64_t)blockIdx.x * RX_TILE + (uint64_t)wave * RX_WAVE_TILE;
+    if (SRC == 0 && wbase + RX_WAVE_TILE <= count) { // full wave tile: all loads in flight before the first atomic
+        ulonglong2 kk[RX_ITEMS / 2];
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        uint64_t g = base + (uint64_t)j * 64;
-        if (g < count) {
-            uint32_t d = SRC == 0 ? (uint32_t)(key[g] >> shift) & 255u : (seg[g] >> shift) & 255u;
-            atomicAdd(&h[d], 1u);
+        for (int j = 0; j < RX_ITEMS / 2; j++)
+            kk[j] = *reinterpret_cast<const ulonglong2 *>(key + wbase + (uint64_t)j * 128 + 2 * lane_id());
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS / 2; j++) {
+            atomicAdd(&h[wave][(uint32_t)(kk[j].x >> shift) & 255u], 1u);
+            atomicAdd(&h[wave][(uint32_t)(kk[j].y >> shift) & 255u], 1u);
+        }
+    } else if (SRC == 0) { // 16-byte loads (two keys per lane): order is irrelevant for counting
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS / 2; j++) {
+            const uint64_t g = wbase + (uint64_t)j * 128 + 2 * lane_id();
+            if (g + 1 < count) {
+                const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + g);
+                atomicAdd(&h[wave][(uint32_t)(kk.x >> shift) & 255u], 1u);
+                atomicAdd(&h[wave][(uint32_t)(kk.y >> shift) & 255u], 1u);
+            } else if (g < count) {
+                atomicAdd(&h[wave][(uint32_t)(key[g] >> shift) & 255u], 1u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS / 4; j++) {
+            const uint64_t g = wbase + (uint64_t)j * 256 + 4 * lane_id();
+            if (g + 3 < count) {
+                const uint4 ss = *reinterpret_cast<const uint4 *>(seg + g);
+                atomicAdd(&h[wave][(ss.x >> shift) & 255u], 1u);
+                atomicAdd(&h[wave][(ss.y >> shift) & 255u], 1u);
+                atomicAdd(&h[wave][(ss.z >> shift) & 255u], 1u);
+                atomicAdd(&h[wave][(ss.w >> shift) & 255u], 1u);
+            } else {
+                for (int e = 0; e < 4; e++)
+                    if (g + e < count) atomicAdd(&h[wave][(seg[g + e] >> shift) & 255u], 1u);
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256) tile_hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x]; // tile-major row
-    (void)tiles;
+    if (threadIdx.x < 256) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < RX_WAVES; w++) t += h[w][threadIdx.x];
+        tile_hist[(uint64_t)blockIdx.x * 256 + threadIdx.x] = t; // tile-major row
+    }
 }
 
 // Scatter.  LDS holds ONE 32 KiB staging buffer that the key, position and segment columns pass through in
