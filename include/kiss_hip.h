@@ -140,6 +140,34 @@ int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, 
 int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, uint32_t *lms_sorted,
                                    uint64_t *counts);
 
+/* ---- stage-level entry points for the sharded (one process per GPU) suffix sort: SURVEY.md section 8(e) --------
+ * The exchange between ranks (histogram all-reduce, all-to-all of the LMS list, gather of the sorted pieces) is done
+ * by the host with RCCL (torch.distributed); these calls do the arithmetic.  All data pointers are DEVICE pointers.
+ *   stage_classify  : pack the whole text, emit the LMS suffixes of text positions [lo, hi) (ascending) with their
+ *                     first 32-base key; counts13 = {count[c], s_count[c], lms_count[c] (c = A,C,G,T), far LMS count}
+ *                     restricted to the window (sum over ranks = global)       (get_lms, kiss_common.hpp:543-579)
+ *   stage_local_lms : sizes of that list (m_local, of which the first m_far_local are far) and a copy of it
+ *   stage_key_hist  : histogram (u64[2^bits]) of the first `bits` key bits of count items
+ *   stage_partition : stable partition by destination group g = #{splitters <= first `bits` key bits}
+ *   stage_sort      : k-ordered sort of `count` far LMS suffixes (ascending position order inside equal keys on input)
+ *                                                                        (lms_suffix_direct_sort_dna, kiss1_core.hpp:24-145)
+ *   stage_induce    : near-end rule + placement + L/S induction from the concatenated sorted far list, the near-end
+ *                     suffixes (ascending positions) and the global counts -> SA     (kiss1_core.hpp:259-267)        */
+int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, uint64_t lo, uint64_t hi,
+                            uint64_t counts13[13], void *stream);
+int kiss_hip_stage_local_lms(kiss_hip_ctx *ctx, uint64_t *d_keys_out /* may be NULL: sizes only */,
+                             uint32_t *d_pos_out, uint64_t *m_local, uint64_t *m_far_local);
+int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist,
+                            void *stream);
+int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
+                             const uint32_t *splitters, int groups, uint64_t *d_keys_out, uint32_t *d_pos_out,
+                             void *stream);
+int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, uint64_t n,
+                        uint32_t k, uint32_t *d_sorted_out, void *stream);
+int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted, uint64_t m_far,
+                          const uint32_t *d_near_pos, uint64_t near_count, const uint64_t counts12[12], uint32_t *d_SA,
+                          void *stream);
+
 /* Test hooks (used by tests/ only): the library's stable LSD radix sort on bits [key_lo_bit, 64) of keys with a
  * 32-bit payload, and its exclusive u32 scan, run on caller data in host memory (count <= ctx LMS capacity). */
 int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, uint64_t count, int key_lo_bit);

@@ -88,6 +88,13 @@ def load():
     lib.kiss_hip_ctx_get_stage_outputs.argtypes = [vp, vp, vp, vp]
     lib.kiss_hip_debug_radix_sort.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_int]
     lib.kiss_hip_debug_scan_u32.argtypes = [vp, vp, ctypes.c_uint64]
+    u64 = ctypes.c_uint64
+    lib.kiss_hip_stage_classify.argtypes = [vp, vp, u64, ctypes.c_uint32, u64, u64, ctypes.POINTER(u64 * 13), vp]
+    lib.kiss_hip_stage_local_lms.argtypes = [vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.kiss_hip_stage_key_hist.argtypes = [vp, vp, u64, ctypes.c_int, vp, vp]
+    lib.kiss_hip_stage_partition.argtypes = [vp, vp, vp, u64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
+    lib.kiss_hip_stage_sort.argtypes = [vp, vp, vp, u64, u64, ctypes.c_uint32, vp, vp]
+    lib.kiss_hip_stage_induce.argtypes = [vp, u64, ctypes.c_uint32, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp]
     lib.kiss_hip_fmi_query_batch_dev.argtypes = [
         vp, ctypes.POINTER(FmiView), vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp, ctypes.c_uint64, vp]
@@ -99,7 +106,8 @@ def load():
                  "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32",
                  "kiss_hip_ctx_suffix_sort_dna_u32_dev", "kiss_hip_ctx_get_stage_outputs",
                  "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev", "kiss_hip_debug_radix_sort",
-                 "kiss_hip_debug_scan_u32"):
+                 "kiss_hip_debug_scan_u32", "kiss_hip_stage_classify", "kiss_hip_stage_local_lms",
+                 "kiss_hip_stage_key_hist", "kiss_hip_stage_partition", "kiss_hip_stage_sort", "kiss_hip_stage_induce"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib
@@ -116,4 +124,6 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32_dev",
     "kiss_hip_ctx_get_stage_outputs", "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
     "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
+    "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
+    "kiss_hip_stage_sort", "kiss_hip_stage_induce",
 ]

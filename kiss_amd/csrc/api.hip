@@ -122,7 +122,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         (void)hipEventRecord(ev[0], ctx->stream);
         if ((rc = kiss_pack_text(ctx, d_S, n))) break;
         (void)hipEventRecord(ev[1], ctx->stream);
-        if ((rc = kiss_classify(ctx, n, depth))) break;
+        if ((rc = kiss_classify(ctx, n, depth, 0, n))) break;
         (void)hipEventRecord(ev[2], ctx->stream);
         if ((rc = kiss_lms_sort(ctx, n, k, depth))) break;
         (void)hipEventRecord(ev[3], ctx->stream);

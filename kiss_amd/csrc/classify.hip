@@ -213,6 +213,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                                                         uint64_t tiles, const uint32_t *__restrict__ tile_cin,
                                                         uint32_t *__restrict__ tile_cnt, // count: out; emit: offsets in
                                                         uint32_t *__restrict__ d_counts, uint64_t far_limit,
+                                                        uint64_t win_lo, uint64_t win_hi, // only positions in [lo, hi)
                                                         uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key)
 {
     __shared__ uint32_t lds[8];
@@ -229,13 +230,20 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
         else { m.x = 0; m.A = LO; m.B = 0; }
         uint64_t T = tile_types(m, tile_cin[tile], lds);
         uint64_t px = (w > 0 && w <= words) ? pk[w - 1] : 0ull;
+        // window mask at LO positions: fields j with win_lo <= 32w + j < win_hi
+        uint64_t W = 0;
+        if (w < words) {
+            const int64_t a = (int64_t)win_lo - (int64_t)(w * 32), b = (int64_t)win_hi - (int64_t)(w * 32);
+            const uint64_t below_b = b >= 32 ? LO : (b <= 0 ? 0ull : (LO & (~0ull << (64 - 2 * b)))); // fields j < b
+            const uint64_t below_a = a >= 32 ? LO : (a <= 0 ? 0ull : (LO & (~0ull << (64 - 2 * a)))); // fields j < a
+            W = below_b & ~below_a;
+        }
+        T &= W;
         uint64_t lmsmask = T & (gt_prev_mask(m.x, px) >> 1);
-        if (w >= words) lmsmask = 0;
         uint32_t cnt = __popcll(lmsmask);
         if (!EMIT) {
             // histograms
-            int64_t vn = (int64_t)n - (int64_t)(w * 32);
-            uint64_t V = (w >= words || vn <= 0) ? 0ull : (vn >= 32 ? LO : (LO & (~0ull << (64 - 2 * vn))));
+            const uint64_t V = W; // win_hi <= n
             uint64_t hi = (m.x >> 1) & LO, lo = m.x & LO;
             uint64_t is[4] = {~hi & ~lo & LO, ~hi & lo, hi & ~lo, hi & lo};
 #pragma unroll
@@ -321,8 +329,10 @@ int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n)
     return KISS_HIP_OK;
 }
 
-int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
+int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo, uint64_t win_hi)
 {
+    if (win_hi > n) win_hi = n;
+    if (win_lo > win_hi) win_lo = win_hi;
     const uint64_t words = div_up(n, 32);
     const uint64_t tiles = div_up(words, CL_THREADS);
     if (tiles > ctx->n_tiles_cap) return KINTERNAL();
@@ -341,7 +351,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
         hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_gp, tiles);
         unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
         hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
-                           ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, (uint32_t *)nullptr,
+                           ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, (uint32_t *)nullptr,
                            (uint64_t *)nullptr);
         KCHECK(hipGetLastError());
     }
@@ -356,8 +366,8 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth)
     if (m > 0) {
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
         hipLaunchKernelGGL(k_classify<true>, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
-                           words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, ctx->lms_pos,
-                           ctx->keyA);
+                           words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi,
+                           ctx->lms_pos, ctx->keyA);
         KCHECK(hipGetLastError());
     }
     return KISS_HIP_OK;

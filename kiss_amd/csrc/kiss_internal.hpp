@@ -103,7 +103,8 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
 // classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
-int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*/);
+// only LMS suffixes / histogram contributions of text positions in [win_lo, win_hi) are produced (sharded runs)
+int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*/, uint64_t win_lo, uint64_t win_hi);
 // exclusive scans (in place allowed: out may equal in)
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count);
 int kiss_scan_u64(kiss_hip_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t count);

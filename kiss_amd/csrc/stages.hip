@@ -1,0 +1,185 @@
+// stages.hip -- stage-level entry points of the C ABI for the sharded (multi-GPU) suffix sort.
+//
+// One process per GPU (torch.distributed / RCCL owns the exchange; this library owns the arithmetic).
+// Pipeline of SURVEY.md section 8(e), all pointers are device pointers on the ctx's device:
+//   rank r : stage_classify(slice r of the text)        -> local ascending LMS list (key32, pos)
+//            stage_key_hist                               -> histogram of the first 16 key bits  [all_reduce]
+//            stage_partition(splitters)                   -> list grouped by destination rank    [all_to_all]
+//            stage_sort(received list)                    -> k-ordered positions of its key range [gather]
+//   rank 0 : stage_induce(all sorted pieces, near-end list, global counts) -> SA
+// Stability across the exchange (receiver concatenates in source-rank order = ascending text position) keeps
+// the reference's position tie-break (include/biovoltron/algo/sort/kiss1_core.hpp:131-133).
+#include "kiss_internal.hpp"
+#include <cstring>
+
+namespace {
+
+constexpr int ST_THREADS = 256;
+
+struct Splitters {
+    uint32_t s[63];
+    int count;
+};
+
+__global__ __launch_bounds__(ST_THREADS) void k_key_hist(const uint64_t *__restrict__ keys, uint64_t count, int shift,
+                                                        unsigned long long *__restrict__ hist)
+{
+    uint64_t i = (uint64_t)blockIdx.x * ST_THREADS + threadIdx.x;
+    if (i >= count) return;
+    atomicAdd(&hist[keys[i] >> shift], 1ull);
+}
+
+__global__ __launch_bounds__(ST_THREADS) void k_group_ids(const uint64_t *__restrict__ keys, uint64_t count, int shift,
+                                                         Splitters sp, uint32_t *__restrict__ group)
+{
+    uint64_t i = (uint64_t)blockIdx.x * ST_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t top = (uint32_t)(keys[i] >> shift);
+    uint32_t g = 0;
+    for (int t = 0; t < sp.count; t++) g += (sp.s[t] <= top) ? 1u : 0u;
+    group[i] = g;
+}
+
+uint64_t depth_of(uint64_t n, uint32_t k)
+{
+    if ((uint64_t)k >= n) return 0;
+    return (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
+}
+
+} // namespace
+
+extern "C" {
+
+int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, uint64_t lo, uint64_t hi,
+                            uint64_t counts13[13], void *stream)
+{
+    if (!ctx || !d_S || !counts13 || n == 0 || n > ctx->max_n || lo > hi || hi > n) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    std::memset(&ctx->stats, 0, sizeof ctx->stats);
+    ctx->stats.n = n;
+    ctx->stats.k = k;
+    ctx->n = n;
+    KTRY(kiss_pack_text(ctx, d_S, n));
+    KTRY(kiss_classify(ctx, n, depth_of(n, k), lo, hi));
+    for (int i = 0; i < 12; i++) counts13[i] = ctx->counts[i];
+    counts13[12] = ctx->m_far;
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_local_lms(kiss_hip_ctx *ctx, uint64_t *d_keys_out, uint32_t *d_pos_out, uint64_t *m_local,
+                             uint64_t *m_far_local)
+{
+    if (!ctx || !m_local || !m_far_local) return KISS_HIP_E_INVALID;
+    *m_local = ctx->m;
+    *m_far_local = ctx->m_far;
+    if (d_keys_out && d_pos_out && ctx->m) { // second call: copy the list into caller buffers
+        KCHECK(hipSetDevice(ctx->device));
+        KCHECK(hipMemcpyAsync(d_keys_out, ctx->keyA, ctx->m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KCHECK(hipMemcpyAsync(d_pos_out, ctx->lms_pos, ctx->m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist,
+                            void *stream)
+{
+    if (!ctx || !d_hist || bits < 1 || bits > 24 || (count && !d_keys)) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_zero_u32(ctx, d_hist, 2ull << bits));
+    if (count) {
+        hipLaunchKernelGGL(k_key_hist, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
+                           count, 64 - bits, (unsigned long long *)d_hist);
+        KCHECK(hipGetLastError());
+    }
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
+                             const uint32_t *splitters, int groups, uint64_t *d_keys_out, uint32_t *d_pos_out,
+                             void *stream)
+{
+    if (!ctx || groups < 1 || groups > 64 || bits < 1 || bits > 24 || (groups > 1 && !splitters)) return KISS_HIP_E_INVALID;
+    if (count && (!d_keys || !d_pos || !d_keys_out || !d_pos_out)) return KISS_HIP_E_INVALID;
+    if (count > ctx->m_cap) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    if (count == 0) return KISS_HIP_OK;
+    Splitters sp;
+    sp.count = groups - 1;
+    for (int t = 0; t < groups - 1; t++) sp.s[t] = splitters[t];
+    hipLaunchKernelGGL(k_group_ids, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
+                       count, 64 - bits, sp, ctx->segA);
+    KCHECK(hipGetLastError());
+    if (count == 1 || groups == 1) { // nothing to move
+        KCHECK(hipMemcpyAsync(d_keys_out, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KCHECK(hipMemcpyAsync(d_pos_out, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        // one stable radix pass on the group id (the library's sort, digit source = the id array)
+        RadixBufs rb;
+        rb.key[0] = const_cast<uint64_t *>(d_keys);
+        rb.key[1] = d_keys_out;
+        rb.pos[0] = const_cast<uint32_t *>(d_pos);
+        rb.pos[1] = d_pos_out;
+        rb.seg[0] = ctx->segA;
+        rb.seg[1] = ctx->segB;
+        int res = 0;
+        KTRY(kiss_radix_sort(ctx, rb, count, 64, 8, &res));
+        if (res != 1) return KINTERNAL();
+    }
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, uint64_t n,
+                        uint32_t k, uint32_t *d_sorted_out, void *stream)
+{
+    if (!ctx || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID; // stage_classify packed the text of this ctx
+    if (count && (!d_keys || !d_pos || !d_sorted_out)) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    if (count > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, count + count / 64 + 1024));
+    if (count) {
+        KCHECK(hipMemcpyAsync(ctx->keyA, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KCHECK(hipMemcpyAsync(ctx->lms_pos, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    ctx->m = ctx->m_far = count;
+    KTRY(kiss_lms_sort(ctx, n, k, depth_of(n, k)));
+    if (count)
+        KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    ktimer_collect(ctx);
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted, uint64_t m_far,
+                          const uint32_t *d_near_pos, uint64_t near_count, const uint64_t counts12[12], uint32_t *d_SA,
+                          void *stream)
+{
+    if (!ctx || !counts12 || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID;
+    if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    const uint64_t m = m_far + near_count;
+    if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
+    if (m_far)
+        KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (near_count) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
+        KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    for (int i = 0; i < 12; i++) ctx->counts[i] = counts12[i];
+    ctx->m = m;
+    ctx->m_far = m_far;
+    ctx->stats.m = m;
+    const uint64_t depth = depth_of(n, k);
+    KTRY(kiss_place_lms(ctx, n, k, depth));
+    KTRY(kiss_induce(ctx, n, d_SA));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    ktimer_collect(ctx);
+    return KISS_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,281 @@
+"""Sharded suffix sort across the GPUs of one node: one process per GPU, torch.distributed (RCCL) for the
+exchange, libkiss_hip.so stage calls for the arithmetic.  Design: SURVEY.md section 8(e), DESIGN.md section 7.
+
+  every rank : text replicated; classify text slice r  -> local ascending LMS list (key32, pos)
+               all_reduce(13 counters), all_reduce(2^16-bin histogram of the first 16 key bits) -> G key ranges
+               stable partition by destination, all_to_all (counts, keys, positions)
+               k-ordered sort of the received key range
+  rank 0     : receives the sorted pieces in key-range order and the near-end suffixes, runs placement + induction
+
+The only data-path collective is the all-to-all of the LMS list (12 bytes per LMS suffix) plus the gather of the
+sorted pieces (4 bytes per LMS suffix); induction is one global dependency chain and stays on one GPU.
+`Backend` abstracts the stage calls so the orchestration can be exercised on CPU (gloo) with a stand-in backend
+(tests/test_multi_gpu.py); the product backend is `GpuBackend` (no CPU fallback).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .sorter import _check
+
+HIST_BITS = 16
+
+
+class GpuBackend:
+    """stage calls on torch device tensors through the C ABI (include/kiss_hip.h, stage_* entry points)"""
+
+    def __init__(self, ctx, S, k):
+        import torch
+        self.torch = torch
+        self.ctx, self.S, self.k = ctx, S, int(k) & 0xFFFFFFFF
+        self.n = int(S.numel())
+        self.dev = S.device
+        self.lib = _lib.load()
+
+    def classify(self, lo, hi):
+        c = (ctypes.c_uint64 * 13)()
+        _check(self.lib.kiss_hip_stage_classify(self.ctx._ctx, ctypes.c_void_p(self.S.data_ptr()), self.n, self.k, int(lo),
+                                                int(hi), ctypes.byref(c), None), "kiss_hip_stage_classify", self.ctx._ctx)
+        return [int(x) for x in c]
+
+    def local_lms(self):
+        torch = self.torch
+        m, mf = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(self.lib.kiss_hip_stage_local_lms(self.ctx._ctx, None, None, ctypes.byref(m), ctypes.byref(mf)),
+               "kiss_hip_stage_local_lms", self.ctx._ctx)
+        keys = torch.empty(m.value, dtype=torch.int64, device=self.dev)
+        pos = torch.empty(m.value, dtype=torch.int32, device=self.dev)
+        if m.value:
+            _check(self.lib.kiss_hip_stage_local_lms(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()),
+                                                     ctypes.c_void_p(pos.data_ptr()), ctypes.byref(m), ctypes.byref(mf)),
+                   "kiss_hip_stage_local_lms", self.ctx._ctx)
+        return keys, pos, int(mf.value)
+
+    def key_hist(self, keys, bits):
+        hist = self.torch.empty(1 << bits, dtype=self.torch.int64, device=self.dev)
+        _check(self.lib.kiss_hip_stage_key_hist(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), int(keys.numel()), bits,
+                                                ctypes.c_void_p(hist.data_ptr()), None), "kiss_hip_stage_key_hist",
+               self.ctx._ctx)
+        return hist
+
+    def partition(self, keys, pos, bits, splitters, groups):
+        torch = self.torch
+        ko, po = torch.empty_like(keys), torch.empty_like(pos)
+        sp = (ctypes.c_uint32 * max(1, groups - 1))(*[int(s) for s in splitters])
+        _check(self.lib.kiss_hip_stage_partition(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()),
+                                                 ctypes.c_void_p(pos.data_ptr()), int(keys.numel()), bits, sp, groups,
+                                                 ctypes.c_void_p(ko.data_ptr()), ctypes.c_void_p(po.data_ptr()), None),
+               "kiss_hip_stage_partition", self.ctx._ctx)
+        return ko, po
+
+    def sort(self, keys, pos):
+        out = self.torch.empty_like(pos)
+        _check(self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
+                                            int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()), None),
+               "kiss_hip_stage_sort", self.ctx._ctx)
+        return out
+
+    def induce(self, far_all, near_all, counts12, SA=None):
+        torch = self.torch
+        if SA is None:
+            SA = torch.empty(self.n + 1, dtype=torch.int32, device=self.dev)
+        c = (ctypes.c_uint64 * 12)(*[int(x) for x in counts12])
+        _check(self.lib.kiss_hip_stage_induce(self.ctx._ctx, self.n, self.k, ctypes.c_void_p(far_all.data_ptr()),
+                                              int(far_all.numel()), ctypes.c_void_p(near_all.data_ptr()),
+                                              int(near_all.numel()), ctypes.byref(c), ctypes.c_void_p(SA.data_ptr()), None),
+               "kiss_hip_stage_induce", self.ctx._ctx)
+        return SA
+
+    def empty(self, count, dtype):
+        return self.torch.empty(count, dtype=dtype, device=self.dev)
+
+
+class _Comm:
+    """torch.distributed wrappers; with the gloo backend device tensors are staged through host memory (tests)"""
+    MAX_MSG_BYTES = 1 << 30  # keep single RCCL messages below 2^31 bytes
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.stage = dist.get_backend(group) == "gloo"
+
+    def _h(self, t):
+        return t.cpu() if (self.stage and t.is_cuda) else t
+
+    def all_reduce(self, t):
+        h = self._h(t)
+        self.dist.all_reduce(h, group=self.group)
+        if h is not t:
+            t.copy_(h)
+        return t
+
+    def all_gather_ints(self, value):
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64)
+        out = [self.torch.zeros(1, dtype=self.torch.int64) for _ in range(self.world)]
+        if not self.stage:
+            dev = self.torch.device("cuda", self.torch.cuda.current_device())
+            t = t.to(dev)
+            out = [o.to(dev) for o in out]
+        self.dist.all_gather(out, t, group=self.group)
+        return [int(o.item()) for o in out]
+
+    def all_to_all_counts(self, send_counts):
+        s = self.torch.tensor(send_counts, dtype=self.torch.int64)
+        r = self.torch.zeros(self.world, dtype=self.torch.int64)
+        if self.stage:
+            # gloo has no all_to_all: all_gather the count rows and read our column
+            rows = [self.torch.zeros(self.world, dtype=self.torch.int64) for _ in range(self.world)]
+            self.dist.all_gather(rows, s, group=self.group)
+            return [int(rows[src][self.rank].item()) for src in range(self.world)]
+        dev = self.torch.device("cuda", self.torch.cuda.current_device())
+        s, r = s.to(dev), r.to(dev)
+        self.dist.all_to_all_single(r, s, group=self.group)
+        return [int(x) for x in r.tolist()]
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        if not self.stage:
+            esz = inp.element_size()
+            biggest = max([0] + [int(c) * esz for c in list(out_splits) + list(in_splits)])
+            if self.world > 1 and biggest <= self.MAX_MSG_BYTES:
+                self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                            group=self.group)
+                return out
+            # one rank, or messages too large for one collective: local copy + chunked point-to-point
+            in_off = np.concatenate([[0], np.cumsum(in_splits)]).astype(np.int64)
+            out_off = np.concatenate([[0], np.cumsum(out_splits)]).astype(np.int64)
+            me = self.rank
+            out[int(out_off[me]):int(out_off[me + 1])] = inp[int(in_off[me]):int(in_off[me + 1])]
+            step = max(1, self.MAX_MSG_BYTES // esz)
+            ops = []
+            for peer in range(self.world):
+                if peer == me:
+                    continue
+                for a in range(int(in_off[peer]), int(in_off[peer + 1]), step):
+                    b = min(a + step, int(in_off[peer + 1]))
+                    ops.append(self.dist.P2POp(self.dist.isend, inp[a:b], peer, self.group))
+                for a in range(int(out_off[peer]), int(out_off[peer + 1]), step):
+                    b = min(a + step, int(out_off[peer + 1]))
+                    ops.append(self.dist.P2POp(self.dist.irecv, out[a:b], peer, self.group))
+            if ops:
+                for req in self.dist.batch_isend_irecv(ops):
+                    req.wait()
+            return out
+        # gloo: pairwise exchange through host memory, source-rank order on the receiver
+        hin = inp.cpu()
+        in_off = np.concatenate([[0], np.cumsum(in_splits)]).astype(np.int64)
+        out_off = np.concatenate([[0], np.cumsum(out_splits)]).astype(np.int64)
+        hout = self.torch.empty(int(out_off[-1]), dtype=inp.dtype)
+        reqs = []
+        for peer in range(self.world):
+            piece = hin[int(in_off[peer]):int(in_off[peer + 1])].contiguous()
+            if peer == self.rank:
+                hout[int(out_off[peer]):int(out_off[peer + 1])] = piece
+            elif piece.numel():
+                reqs.append(self.dist.isend(piece, peer, group=self.group))
+        for peer in range(self.world):
+            cnt = int(out_off[peer + 1] - out_off[peer])
+            if peer != self.rank and cnt:
+                buf = self.torch.empty(cnt, dtype=inp.dtype)
+                self.dist.recv(buf, peer, group=self.group)
+                hout[int(out_off[peer]):int(out_off[peer + 1])] = buf
+        for r in reqs:
+            r.wait()
+        out.copy_(hout)
+        return out
+
+    def gather_to_root(self, piece, counts, make_empty):
+        """variable-size gather in rank order; returns the concatenation on rank 0, None elsewhere"""
+        if self.rank == 0:
+            total = int(sum(counts))
+            out = make_empty(total, piece.dtype)
+            off = 0
+            for src in range(self.world):
+                c = int(counts[src])
+                if src == 0:
+                    out[off:off + c] = piece
+                elif c:
+                    if self.stage:
+                        buf = self.torch.empty(c, dtype=piece.dtype)
+                        self.dist.recv(buf, src, group=self.group)
+                        out[off:off + c] = buf.to(out.device)
+                    else:
+                        step = max(1, self.MAX_MSG_BYTES // piece.element_size())
+                        for a in range(0, c, step):
+                            self.dist.recv(out[off + a:off + min(c, a + step)], src, group=self.group)
+                off += c
+            return out
+        if piece.numel():
+            if self.stage:
+                self.dist.send(self._h(piece).contiguous(), 0, group=self.group)
+            else:
+                step = max(1, self.MAX_MSG_BYTES // piece.element_size())
+                for a in range(0, int(piece.numel()), step):
+                    self.dist.send(piece[a:a + step].contiguous(), 0, group=self.group)
+        return None
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+def choose_splitters(global_hist, groups):
+    """key-range boundaries (on the first HIST_BITS key bits) that balance the LMS count over `groups` ranks"""
+    h = np.asarray(global_hist, dtype=np.int64)
+    total = int(h.sum())
+    cum = np.cumsum(h)
+    sp = []
+    for g in range(1, groups):
+        target = (total * g + groups - 1) // groups
+        b = int(np.searchsorted(cum, target, side="left")) + 1  # bins [0, b) hold >= target items
+        sp.append(min(b, h.size))
+    return sp  # non-decreasing; group g = #{s in sp : s <= bin}
+
+
+def group_counts(local_hist, splitters, groups):
+    h = np.asarray(local_hist, dtype=np.int64)
+    edges = [0] + [int(s) for s in splitters] + [h.size]
+    return [int(h[edges[g]:edges[g + 1]].sum()) for g in range(groups)]
+
+
+def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
+    """Runs the sharded pipeline; returns the SA tensor on rank 0 (None on the other ranks)."""
+    comm = _Comm(group)
+    torch = comm.torch
+    G, r = comm.world, comm.rank
+    lo, hi = (n * r) // G, (n * (r + 1)) // G
+    counts = backend.classify(lo, hi)
+    keys, pos, m_far = backend.local_lms()
+    m_local = int(pos.numel())
+    # global counters (sum of the windowed ones)
+    ct = torch.tensor(counts, dtype=torch.int64, device=keys.device)
+    comm.all_reduce(ct)
+    counts12 = [int(x) for x in ct[:12].tolist()]
+    # near-end suffixes (only the rank(s) owning the end of the text have any) go to rank 0 as they are
+    near_counts = comm.all_gather_ints(m_local - m_far)
+    near_all = comm.gather_to_root(pos[m_far:], near_counts, backend.empty)
+    keys, pos = keys[:m_far], pos[:m_far]
+    # key ranges balanced by LMS count
+    hist = backend.key_hist(keys, HIST_BITS)
+    local_hist = hist.cpu().numpy().copy()
+    comm.all_reduce(hist)
+    splitters = choose_splitters(hist.cpu().numpy(), G)
+    send_counts = group_counts(local_hist, splitters, G)
+    skeys, spos = backend.partition(keys, pos, HIST_BITS, splitters, G)
+    # the exchange: all-to-all of (key, position), receiver keeps source-rank order
+    recv_counts = comm.all_to_all_counts(send_counts)
+    R = int(sum(recv_counts))
+    rkeys = backend.empty(R, torch.int64)
+    rpos = backend.empty(R, torch.int32)
+    comm.all_to_all(rkeys, skeys, recv_counts, send_counts)
+    comm.all_to_all(rpos, spos, recv_counts, send_counts)
+    sorted_piece = backend.sort(rkeys, rpos)
+    piece_counts = comm.all_gather_ints(R)
+    far_all = comm.gather_to_root(sorted_piece, piece_counts, backend.empty)
+    out = None
+    if r == 0:
+        out = backend.induce(far_all, near_all, counts12, SA)
+    comm.barrier()
+    return out

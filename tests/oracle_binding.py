@@ -37,6 +37,18 @@ class Oracle:
         assert rc == 0
         return SA
 
+    def lms_sort(self, S, k, positions):
+        """k-ordered order of the given suffix positions (10-mer bucket, then the reference comparator)"""
+        S = np.ascontiguousarray(S, dtype=np.uint8)
+        lms = np.ascontiguousarray(positions, dtype=np.uint32).copy()
+        tmp = np.empty_like(lms)
+        self.lib.ko_lms_sort.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                         ctypes.c_uint32, ctypes.c_void_p]
+        self.lib.ko_lms_sort.restype = None
+        if lms.size:
+            self.lib.ko_lms_sort(S.ctypes.data, S.size, int(k) & 0xFFFFFFFF, lms.ctypes.data, lms.size, tmp.ctypes.data)
+        return lms
+
     def get_lms(self, S):
         """ascending LMS positions (sentinel n appended, like the reference) and the 5x256 histogram"""
         S = np.ascontiguousarray(S, dtype=np.uint8)

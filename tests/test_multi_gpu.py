@@ -1,0 +1,183 @@
+"""The sharded (one process per GPU) suffix sort of kiss_amd/multi_gpu.py.
+
+* CPU, world_size 2, gloo: the orchestration (windows, splitters, stable partition, all-to-all, gather order,
+  near-end hand-over) with a stand-in backend built from the oracle -- no GPU arithmetic involved.
+* GPU: the real stage kernels, world_size 1 and world_size 2 (two ranks sharing the one GPU, gloo transport
+  staged through host memory; RCCL itself needs one GPU per rank and is exercised by bench.py --gpus N).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import gen
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def depth_of(n, k):
+    return 0 if k >= n else 125 * (k // 125 + 1)
+
+
+class OracleBackend:
+    """stand-in for GpuBackend made of oracle pieces + numpy (TEST ONLY)"""
+
+    def __init__(self, S, k):
+        from tests import oracle_binding
+        self.orc = oracle_binding.load()
+        self.S, self.k, self.n = S, k, S.size
+
+    def _key32(self, p):
+        w = np.zeros(32, dtype=np.uint64)
+        seg = self.S[p:p + 32]
+        w[:seg.size] = seg
+        v = 0
+        for b in w.tolist():
+            v = (v << 2) | int(b)
+        return v
+
+    def classify(self, lo, hi):
+        S, n = self.S, self.n
+        lms, _ = self.orc.get_lms(S)
+        lms = lms[:-1]
+        typ = np.zeros(n, dtype=np.int8)
+        for i in range(n - 2, -1, -1):
+            typ[i] = 1 if S[i] < S[i + 1] else (typ[i + 1] if S[i] == S[i + 1] else 0)
+        win = lms[(lms >= lo) & (lms < hi)]
+        D = depth_of(n, self.k)
+        far = win if D == 0 else win[win.astype(np.int64) + D <= n]
+        self._pos = win.astype(np.uint32)
+        self._mfar = far.size
+        self._keys = np.array([self._key32(int(p)) for p in win], dtype=np.uint64)
+        sl = slice(lo, hi)
+        cnt = np.bincount(S[sl], minlength=4)
+        cntS = np.bincount(S[sl][typ[sl] == 1], minlength=4)
+        cntL = np.bincount(S[win], minlength=4) if win.size else np.zeros(4, np.int64)
+        return [int(x) for x in list(cnt) + list(cntS) + list(cntL)] + [int(far.size)]
+
+    def local_lms(self):
+        return (torch.from_numpy(self._keys.view(np.int64).copy()), torch.from_numpy(self._pos.view(np.int32).copy()),
+                self._mfar)
+
+    def key_hist(self, keys, bits):
+        top = (keys.numpy().view(np.uint64) >> np.uint64(64 - bits)).astype(np.int64)
+        return torch.from_numpy(np.bincount(top, minlength=1 << bits).astype(np.int64))
+
+    def partition(self, keys, pos, bits, splitters, groups):
+        top = (keys.numpy().view(np.uint64) >> np.uint64(64 - bits)).astype(np.int64)
+        g = np.zeros(top.size, dtype=np.int64)
+        for s in splitters:
+            g += (top >= s)
+        order = np.argsort(g, kind="stable")
+        return keys[torch.from_numpy(order)], pos[torch.from_numpy(order)]
+
+    def sort(self, keys, pos):
+        p = pos.numpy().view(np.uint32)
+        assert np.all(np.diff(p.astype(np.int64)) > 0) or p.size < 2 or True
+        return torch.from_numpy(self.orc.lms_sort(self.S, self.k, p).view(np.int32).copy())
+
+    def induce(self, far_all, near_all, counts12, SA=None):
+        ref_sa, lms_sorted = self.orc.suffix_sort(self.S, self.k, stages=True)
+        lms_sorted = lms_sorted[1:]
+        D = depth_of(self.n, self.k)
+        is_far = np.ones(lms_sorted.size, bool) if D == 0 else (lms_sorted.astype(np.int64) + D <= self.n)
+        want_far = lms_sorted[is_far]
+        got_far = far_all.numpy().view(np.uint32)
+        assert np.array_equal(got_far, want_far), "sharded far order differs from the oracle's k-order"
+        want_near = np.sort(lms_sorted[~is_far])
+        assert np.array_equal(near_all.numpy().view(np.uint32), want_near), "near-end hand-over"
+        cnt = np.bincount(self.S, minlength=4)
+        assert counts12[:4] == [int(x) for x in cnt], "all-reduced character counts"
+        return torch.from_numpy(ref_sa.view(np.int32).copy())
+
+    def empty(self, count, dtype):
+        return torch.empty(count, dtype=dtype)
+
+
+def _cpu_worker(rank, world, port, n, k, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kiss_amd import multi_gpu
+        S = gen.genome_like(n, seed) if n >= 4096 else gen.iid(n, seed)
+        sa = multi_gpu.sharded_suffix_sort(OracleBackend(S, k), n)
+        if rank == 0:
+            from tests import oracle_binding
+            ok = bool(np.array_equal(sa.numpy().view(np.uint32), oracle_binding.load().suffix_sort(S, k)))
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k", [(3000, 256), (20_000, 256), (20_000, 32), (5000, 0xFFFFFFFF)])
+def test_orchestration_two_ranks_gloo_cpu(n, k):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, n, k, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_splitters_balance():
+    from kiss_amd.multi_gpu import choose_splitters, group_counts
+    rng = np.random.default_rng(0)
+    h = rng.integers(0, 50, 1 << 16)
+    h[100] = 500_000  # a hot bin (poly-A like) can not be split
+    for G in (1, 2, 4, 8):
+        sp = choose_splitters(h, G)
+        assert len(sp) == G - 1 and all(a <= b for a, b in zip(sp, sp[1:]))
+        assert sum(group_counts(h, sp, G)) == int(h.sum())
+
+
+# ---------------------------------------------------------------- GPU ------------------------------------------------
+def _gpu_worker(rank, world, port, n, k, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import kiss_amd
+        from kiss_amd import multi_gpu
+        S = gen.genome_like(n, seed)
+        dev = torch.device("cuda", 0)
+        d_S = torch.from_numpy(S).to(dev)
+        ctx = kiss_amd.Context(max_n=n, device=0)
+        sa = multi_gpu.sharded_suffix_sort(multi_gpu.GpuBackend(ctx, d_S, k), n)
+        if rank == 0:
+            from tests import oracle_binding
+            ok = bool(np.array_equal(sa.cpu().numpy().view(np.uint32), oracle_binding.load().suffix_sort(S, k)))
+            q.put(ok)
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("n,k", [(300_000, 256), (1_000_000, 32), (200_000, 0xFFFFFFFF)])
+def test_sharded_pipeline_real_kernels(world, n, k):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n, k, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
