@@ -119,7 +119,8 @@ def main():
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=500_000_000,
+                    help="bases of the CPU baseline sample (0 = skip); 5e8 bases = ~15-20 s of oracle time on the GPU box")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: 'sharded' = ONE text, LMS sort sharded by key range over the ranks with an RCCL "
