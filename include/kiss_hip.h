@@ -215,6 +215,22 @@ int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, co
                            uint8_t *d_bwt, uint32_t *d_occ1, uint8_t *d_occ2, uint32_t *d_sa_sampled, uint64_t *d_b,
                            uint32_t *d_b_occ, uint32_t cnt_out[4], uint32_t *pri_out, void *stream);
 
+/* Host-pointer forms of the two FM-index calls (create a ctx on `device`, upload, run, download, free): what a host
+ * that does not link HIP binds -- the `kiss` CLI (kiss_amd/csrc/host/kiss_cli.cpp), cgo / ctypes callers.
+ * kiss_hip_fmi_build_host: SA_or_null == NULL sorts with k = 32 first, like FMIndex::build(ref) (fm_index.hpp:379-387).
+ * Array sizes for a text of n bases: kiss_hip_fmi_sizes_for (the .fmi layout of fm_index.hpp:591-615). */
+typedef struct kiss_hip_fmi_sizes {
+    uint64_t n_sa, bwt_bytes, occ1_entries, occ2_bytes, sa_entries, b_words, b_occ_entries;
+} kiss_hip_fmi_sizes;
+int kiss_hip_fmi_sizes_for(uint64_t n, kiss_hip_fmi_sizes *out);
+int kiss_hip_fmi_build_host(const uint8_t *S, uint64_t n, const uint32_t *SA_or_null, uint8_t *bwt, uint32_t *occ1,
+                            uint8_t *occ2, uint32_t *sa, uint64_t *b, uint32_t *b_occ, uint32_t cnt_out[4],
+                            uint32_t *pri_out, int device);
+int kiss_hip_fmi_query_batch_host(const kiss_hip_fmi_view *fmi, const uint8_t *patterns, uint32_t L, uint64_t Q,
+                                  uint32_t *beg, uint32_t *end, uint64_t *hit_count_total, uint64_t *checksum,
+                                  uint32_t *offsets, uint64_t *offsets_index, uint64_t offsets_capacity, int device);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,4 +126,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
     "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
     "kiss_hip_stage_sort", "kiss_hip_stage_induce",
+    "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
 ]

@@ -447,4 +447,111 @@ int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, co
     }
     return KISS_HIP_OK;
 }
+
+// ---- host-pointer forms (hosts that do not link HIP: the CLI, cgo/ctypes callers) -----------------------
+int kiss_hip_fmi_sizes_for(uint64_t n, kiss_hip_fmi_sizes *out)
+{
+    if (!out || n > KISS_HIP_MAX_N) return KISS_HIP_E_INVALID;
+    const uint64_t N = n + 1;
+    out->n_sa = N;
+    out->bwt_bytes = (N + 3) / 4;
+    out->occ1_entries = (N / 256 + 1) * 4;
+    out->occ2_bytes = (N / 16 + 1) * 4;
+    out->sa_entries = (N + 3) / 4;
+    out->b_words = (N + 63) / 64;
+    out->b_occ_entries = N / 64 + 1;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_fmi_build_host(const uint8_t *S, uint64_t n, const uint32_t *SA_or_null, uint8_t *bwt, uint32_t *occ1,
+                            uint8_t *occ2, uint32_t *sa, uint64_t *b, uint32_t *b_occ, uint32_t cnt_out[4],
+                            uint32_t *pri_out, int device)
+{
+    if (!S || !bwt || !occ1 || !occ2 || !sa || !b || !b_occ || !cnt_out || !pri_out || n == 0) return KISS_HIP_E_INVALID;
+    kiss_hip_fmi_sizes z;
+    KTRY(kiss_hip_fmi_sizes_for(n, &z));
+    kiss_hip_ctx *ctx = nullptr;
+    int rc = kiss_hip_ctx_create(&ctx, device, n);
+    if (rc) return rc;
+    DevBuf dS, dSA, dbwt, docc1, docc2, dsa, db, dbocc;
+    do {
+        if ((rc = dS.alloc(ctx, n)) || (rc = dSA.alloc(ctx, (n + 1) * 4)) || (rc = dbwt.alloc(ctx, z.bwt_bytes + 8)) ||
+            (rc = docc1.alloc(ctx, z.occ1_entries * 4)) || (rc = docc2.alloc(ctx, z.occ2_bytes)) ||
+            (rc = dsa.alloc(ctx, z.sa_entries * 4)) || (rc = db.alloc(ctx, z.b_words * 8 + 8)) ||
+            (rc = dbocc.alloc(ctx, z.b_occ_entries * 4)))
+            break;
+        if (hipMemcpy(dS.p, S, n, hipMemcpyHostToDevice) != hipSuccess) { rc = KISS_HIP_E_HIP; break; }
+        if (SA_or_null) {
+            if (hipMemcpy(dSA.p, SA_or_null, (n + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = KISS_HIP_E_HIP; break; }
+        } else {
+            // FMIndex::build sorts with k = 32 whatever the caller's flags say (fm_index.hpp:384-386)
+            if ((rc = kiss_hip_ctx_suffix_sort_dna_u32_dev(ctx, (const uint8_t *)dS.p, n, 32u, KISS_HIP_ALGO_PARALLEL_SORTING,
+                                                           (uint32_t *)dSA.p, nullptr)))
+                break;
+        }
+        if ((rc = kiss_hip_fmi_build_dev(ctx, (const uint8_t *)dS.p, n, (const uint32_t *)dSA.p, 4, (uint8_t *)dbwt.p,
+                                         (uint32_t *)docc1.p, (uint8_t *)docc2.p, (uint32_t *)dsa.p, (uint64_t *)db.p,
+                                         (uint32_t *)dbocc.p, cnt_out, pri_out, nullptr)))
+            break;
+        hipError_t e = hipMemcpy(bwt, dbwt.p, z.bwt_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(occ1, docc1.p, z.occ1_entries * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(occ2, docc2.p, z.occ2_bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(sa, dsa.p, z.sa_entries * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(b, db.p, z.b_words * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(b_occ, dbocc.p, z.b_occ_entries * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = KISS_HIP_E_HIP;
+    } while (0);
+    kiss_hip_ctx_destroy(ctx);
+    return rc;
+}
+
+int kiss_hip_fmi_query_batch_host(const kiss_hip_fmi_view *fmi, const uint8_t *patterns, uint32_t L, uint64_t Q,
+                                  uint32_t *beg, uint32_t *end, uint64_t *hit_count_total, uint64_t *checksum,
+                                  uint32_t *offsets, uint64_t *offsets_index, uint64_t offsets_capacity, int device)
+{
+    if (!fmi || !beg || !end || (Q && !patterns) || fmi->n_sa == 0) return KISS_HIP_E_INVALID;
+    kiss_hip_fmi_sizes z;
+    KTRY(kiss_hip_fmi_sizes_for(fmi->n_sa - 1, &z));
+    kiss_hip_ctx *ctx = nullptr;
+    uint64_t max_n = fmi->n_sa > 4 * Q ? fmi->n_sa : 4 * Q;
+    if (max_n < (1u << 20)) max_n = 1u << 20;
+    int rc = kiss_hip_ctx_create(&ctx, device, max_n);
+    if (rc) return rc;
+    DevBuf dbwt, docc1, docc2, dsa, db, dbocc, dpat, dbeg, dend, doff, didx;
+    do {
+        if ((rc = dbwt.alloc(ctx, z.bwt_bytes + 8)) || (rc = docc1.alloc(ctx, z.occ1_entries * 4)) ||
+            (rc = docc2.alloc(ctx, z.occ2_bytes)) || (rc = dsa.alloc(ctx, z.sa_entries * 4)) ||
+            (rc = db.alloc(ctx, z.b_words * 8 + 8)) || (rc = dbocc.alloc(ctx, z.b_occ_entries * 4)) ||
+            (rc = dpat.alloc(ctx, Q * L)) || (rc = dbeg.alloc(ctx, Q * 4)) || (rc = dend.alloc(ctx, Q * 4)))
+            break;
+        hipError_t e = hipMemcpy(dbwt.p, fmi->bwt, z.bwt_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(docc1.p, fmi->occ1, z.occ1_entries * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(docc2.p, fmi->occ2, z.occ2_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dsa.p, fmi->sa, z.sa_entries * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(db.p, fmi->b, z.b_words * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dbocc.p, fmi->b_occ, z.b_occ_entries * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && Q) e = hipMemcpy(dpat.p, patterns, Q * L, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = KISS_HIP_E_HIP; break; }
+        kiss_hip_fmi_view v = *fmi;
+        v.bwt = (const uint8_t *)dbwt.p;
+        v.occ1 = (const uint32_t *)docc1.p;
+        v.occ2 = (const uint8_t *)docc2.p;
+        v.sa = (const uint32_t *)dsa.p;
+        v.b = (const uint64_t *)db.p;
+        v.b_occ = (const uint32_t *)dbocc.p;
+        const bool want = offsets && offsets_index && offsets_capacity;
+        if (want && ((rc = doff.alloc(ctx, offsets_capacity * 4)) || (rc = didx.alloc(ctx, (Q + 1) * 8)))) break;
+        if ((rc = kiss_hip_fmi_query_batch_dev(ctx, &v, (const uint8_t *)dpat.p, L, Q, (uint32_t *)dbeg.p, (uint32_t *)dend.p,
+                                               hit_count_total, checksum, want ? (uint32_t *)doff.p : nullptr,
+                                               want ? (uint64_t *)didx.p : nullptr, want ? offsets_capacity : 0, nullptr)))
+            break;
+        e = hipMemcpy(beg, dbeg.p, Q * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(end, dend.p, Q * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && want) e = hipMemcpy(offsets_index, didx.p, (Q + 1) * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && want) e = hipMemcpy(offsets, doff.p, offsets_capacity * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = KISS_HIP_E_HIP;
+    } while (0);
+    kiss_hip_ctx_destroy(ctx);
+    return rc;
+}
 }

@@ -1,0 +1,345 @@
+// kiss_cli.cpp -- `kiss`: the kISS command line on top of libkiss_hip.so (host C++17, no HIP, no Boost).
+//
+// Keeps the reference's CLI surface (reference include/utils/options.hpp:83-203, src/main.cpp:19-39):
+//   kiss [-h] [-v] [-g] [-t NUM] [--verbose] <command> [options] <FASTA filename/Text filename>
+//   suffix_sort    [-k NUM(=256, -1 = unbounded)] [-s PARALLEL_SORTING|PREFIX_DOUBLING]   (command/suffix_sort.hpp)
+//   fmindex_build  [-k NUM (ignored, like the reference)]  -> writes <fasta>.fmi            (command/fmindex_build.hpp)
+//   fmindex_query  [-q STR] [-n NUM(=10)] [-b patterns.bin]                                  (command/fmindex_query.hpp)
+// and its log fields ("n = …, k = …, suffix sorting elapsed …", "query = … found N times", "searching time",
+// "number of matched locations", "location checksum").  Extras (opt-in): --output-sa FILE (raw u32 LE, n+1
+// entries; the reference never writes the SA), --device N.
+// Input handling as utils/io.hpp:6-18 + suffix_sort.hpp:33: FASTA if the first byte is '>' (all records
+// concatenated), else plain text lines; ACGT/acgt -> 0..3, every other character -> 4 % 4 = 0 (A).
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/kiss_hip.h"
+
+namespace {
+
+const char *VERSION = "1.0.0-hip";
+
+void usage()
+{
+    std::cerr << "kiss " << VERSION << " (MI355X / libkiss_hip)\n"
+              << "kiss [--generic-option ...] cmd [--cmd-specific-option ...]\n"
+              << "Generic options:\n"
+              << "  -h [ --help ]            produce help message\n"
+              << "  -v [ --version ]         print version string\n"
+              << "  -g [ --generic ]         (not supported) generic alphabet\n"
+              << "  -t [ --num_threads ] NUM accepted for compatibility; no result depends on it\n"
+              << "  --verbose                print per-stage device times\n"
+              << "  --device NUM             HIP device index (default 0)\n\n"
+              << "./kiss suffix_sort [--option ...] <FASTA filename/Text filename>\n"
+              << "  -k [ --kordered ] NUM (=256)   k-ordered value; -1 indicates unbounded sorting\n"
+              << "  -s [ --sorting-algorithm ] ALGO (=PARALLEL_SORTING)   PARALLEL_SORTING or PREFIX_DOUBLING\n"
+              << "  --output-sa FILE               also write the suffix array (raw uint32 LE, n+1 entries)\n\n"
+              << "./kiss fmindex_build [--option ...] <FASTA filename/Text filename>\n"
+              << "  -k [ --kordered ] NUM (=256)   accepted and ignored (the index is built with k = 32)\n\n"
+              << "./kiss fmindex_query [--option ...] <FASTA filename/Text filename>\n"
+              << "  -q [ --query ] STR             content of the query string\n"
+              << "  -n [ --headn ] NUM (=10)       output the first n locations in single query mode\n"
+              << "  -b [ --batch ] patterns.bin    batch query mode (u32 len, u32 count, then count x len bytes)\n";
+}
+
+inline uint8_t to_code(unsigned char c)
+{
+    switch (c) {
+    case 'a': case 'A': return 0;
+    case 'c': case 'C': return 1;
+    case 'g': case 'G': return 2;
+    case 't': case 'T': return 3;
+    default: return 0; // Codec::to_int gives 4, the commands apply % 4 (suffix_sort.hpp:33)
+    }
+}
+
+// utils/io.hpp:6-18
+std::vector<uint8_t> read_sequence(const std::string &path)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open " + path);
+    std::vector<uint8_t> seq;
+    std::string line;
+    const bool fasta = in.peek() == '>';
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (fasta && !line.empty() && line[0] == '>') continue;
+        for (unsigned char c : line) seq.push_back(to_code(c));
+    }
+    return seq;
+}
+
+void check(int rc, const char *where)
+{
+    if (rc != KISS_HIP_OK) throw std::runtime_error(std::string(where) + ": " + kiss_hip_strerror(rc));
+}
+
+struct Args {
+    std::string command, fasta, query, batch, output_sa, algo = "PARALLEL_SORTING";
+    long long k = 256;
+    size_t headn = 10;
+    int device = 0;
+    bool verbose = false, generic = false;
+};
+
+Args parse(int argc, char **argv)
+{
+    Args a;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; i++) {
+        std::string s = argv[i];
+        auto next = [&](const char *name) -> std::string {
+            if (i + 1 >= argc) throw std::runtime_error(std::string("the required argument for option '") + name + "' is missing");
+            return argv[++i];
+        };
+        if (s == "-h" || s == "--help") { usage(); std::exit(1); }
+        else if (s == "-v" || s == "--version") { std::cerr << VERSION << std::endl; std::exit(1); }
+        else if (s == "-g" || s == "--generic") a.generic = true;
+        else if (s == "--verbose") a.verbose = true;
+        else if (s == "-t" || s == "--num_threads") (void)next("--num_threads");
+        else if (s == "--device") a.device = std::stoi(next("--device"));
+        else if (s == "-k" || s == "--kordered") a.k = std::stoll(next("--kordered"));
+        else if (s == "-s" || s == "--sorting-algorithm") a.algo = next("--sorting-algorithm");
+        else if (s == "-q" || s == "--query") a.query = next("--query");
+        else if (s == "-n" || s == "--headn") a.headn = (size_t)std::stoull(next("--headn"));
+        else if (s == "-b" || s == "--batch") a.batch = next("--batch");
+        else if (s == "--output-sa") a.output_sa = next("--output-sa");
+        else if (!s.empty() && s[0] == '-' && s.size() > 1) throw std::runtime_error("unrecognised option '" + s + "'");
+        else pos.push_back(s);
+    }
+    if (pos.empty()) { usage(); std::exit(1); }
+    a.command = pos[0];
+    if (pos.size() < 2) throw std::runtime_error("the option '--fasta' is required but missing");
+    a.fasta = pos[1];
+    std::transform(a.algo.begin(), a.algo.end(), a.algo.begin(), [](unsigned char c) { return (char)std::toupper(c); });
+    return a;
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// ---- .fmi (fm_index.hpp:591-646; Serializer: u64 count + raw bytes, nothing when the count is 0) ----------
+struct Fmi {
+    kiss_hip_fmi_sizes z{};
+    uint32_t cnt[4]{}, pri = 0;
+    std::vector<uint8_t> bwt, occ2;
+    std::vector<uint32_t> occ1, sa, b_occ;
+    std::vector<uint64_t> b;
+    void alloc(uint64_t n)
+    {
+        check(kiss_hip_fmi_sizes_for(n, &z), "kiss_hip_fmi_sizes_for");
+        bwt.assign(z.bwt_bytes, 0);
+        occ1.assign(z.occ1_entries, 0);
+        occ2.assign(z.occ2_bytes, 0);
+        sa.assign(z.sa_entries, 0);
+        b.assign(z.b_words, 0);
+        b_occ.assign(z.b_occ_entries, 0);
+    }
+    static void put(std::ofstream &o, uint64_t count, const void *p, uint64_t bytes)
+    {
+        if (!count) return;
+        o.write(reinterpret_cast<const char *>(&count), 8);
+        o.write(reinterpret_cast<const char *>(p), (std::streamsize)bytes);
+    }
+    void save(const std::string &path) const
+    {
+        std::ofstream o(path, std::ios::binary);
+        if (!o) throw std::runtime_error("cannot write " + path);
+        o.write(reinterpret_cast<const char *>(cnt), 16);
+        o.write(reinterpret_cast<const char *>(&pri), 4);
+        put(o, z.n_sa, bwt.data(), z.bwt_bytes);
+        put(o, z.occ1_entries / 4, occ1.data(), z.occ1_entries * 4);
+        put(o, z.occ2_bytes / 4, occ2.data(), z.occ2_bytes);
+        put(o, z.sa_entries, sa.data(), z.sa_entries * 4);
+        const uint32_t lookup[2] = {0u, (uint32_t)z.n_sa}; // LOOKUP_LEN = 0 (fm_index.hpp:238-258)
+        put(o, 2, lookup, 8);
+        put(o, z.n_sa, b.data(), z.b_words * 8);
+        put(o, z.b_occ_entries, b_occ.data(), z.b_occ_entries * 4);
+    }
+    static uint64_t get_count(std::ifstream &in)
+    {
+        uint64_t c = 0;
+        in.read(reinterpret_cast<char *>(&c), 8);
+        if (!in) throw std::runtime_error("truncated .fmi");
+        return c;
+    }
+    void load(const std::string &path)
+    {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw std::runtime_error("cannot open " + path + " (run fmindex_build first)");
+        in.read(reinterpret_cast<char *>(cnt), 16);
+        in.read(reinterpret_cast<char *>(&pri), 4);
+        const uint64_t N = get_count(in);
+        alloc(N - 1);
+        in.read(reinterpret_cast<char *>(bwt.data()), (std::streamsize)z.bwt_bytes);
+        if (get_count(in) * 4 != z.occ1_entries) throw std::runtime_error("bad occ1 size in .fmi");
+        in.read(reinterpret_cast<char *>(occ1.data()), (std::streamsize)(z.occ1_entries * 4));
+        if (get_count(in) * 4 != z.occ2_bytes) throw std::runtime_error("bad occ2 size in .fmi");
+        in.read(reinterpret_cast<char *>(occ2.data()), (std::streamsize)z.occ2_bytes);
+        if (get_count(in) != z.sa_entries) throw std::runtime_error("bad sa size in .fmi");
+        in.read(reinterpret_cast<char *>(sa.data()), (std::streamsize)(z.sa_entries * 4));
+        if (get_count(in) != 2) throw std::runtime_error("bad lookup size in .fmi (LOOKUP_LEN = 0 expected)");
+        uint32_t lookup[2];
+        in.read(reinterpret_cast<char *>(lookup), 8);
+        if (get_count(in) != N) throw std::runtime_error("bad b_ size in .fmi");
+        in.read(reinterpret_cast<char *>(b.data()), (std::streamsize)(z.b_words * 8));
+        if (get_count(in) != z.b_occ_entries) throw std::runtime_error("bad b_occ_ size in .fmi");
+        in.read(reinterpret_cast<char *>(b_occ.data()), (std::streamsize)(z.b_occ_entries * 4));
+        if (!in || in.peek() != EOF) throw std::runtime_error("trailing or missing bytes in .fmi"); // fm_index.hpp:642
+    }
+    kiss_hip_fmi_view view() const
+    {
+        kiss_hip_fmi_view v{};
+        v.n_sa = z.n_sa;
+        for (int c = 0; c < 4; c++) v.cnt[c] = cnt[c];
+        v.pri = pri;
+        v.sa_intv = 4;
+        v.bwt = bwt.data();
+        v.occ1 = occ1.data();
+        v.occ2 = occ2.data();
+        v.sa = sa.data();
+        v.b = b.data();
+        v.b_occ = b_occ.data();
+        return v;
+    }
+};
+
+int suffix_sort_main(const Args &a)
+{
+    auto S = read_sequence(a.fasta);
+    int algo;
+    if (a.algo == "PARALLEL_SORTING") algo = KISS_HIP_ALGO_PARALLEL_SORTING;
+    else if (a.algo == "PREFIX_DOUBLING") algo = KISS_HIP_ALGO_PREFIX_DOUBLING;
+    else throw std::invalid_argument("Invalid sorting algorithm");
+    const uint32_t k = (uint32_t)(uint64_t)a.k; // -1 -> size_t max -> truncated to 0xFFFFFFFF (suffix_sort.hpp:35-37)
+    std::vector<uint32_t> SA(S.size() + 1);
+    const auto t0 = std::chrono::steady_clock::now(); // the reference starts its stopwatch here (suffix_sort.hpp:57)
+    kiss_hip_ctx *ctx = nullptr;
+    if (S.empty()) SA[0] = 0;
+    else {
+        check(kiss_hip_ctx_create(&ctx, a.device, S.size()), "kiss_hip_ctx_create");
+        check(kiss_hip_ctx_suffix_sort_dna_u32(ctx, S.data(), S.size(), k, algo, SA.data()), "kiss_hip_ctx_suffix_sort_dna_u32");
+    }
+    const double el = seconds_since(t0);
+    std::fprintf(stderr, "[info] n = %zu, k = %llu, suffix sorting elapsed %.6f\n", S.size(),
+                 (unsigned long long)(a.k < 0 ? ~0ull : (unsigned long long)a.k), el);
+    if (a.verbose && ctx) {
+        kiss_hip_stats st;
+        kiss_hip_get_stats(ctx, &st);
+        std::fprintf(stderr,
+                     "[debug] device: pack %.3f ms, get_lms %.3f ms, lms_suffix_direct_sort %.3f ms, put_lms_suffix %.3f ms, "
+                     "induced_sort %.3f ms, total %.3f ms; lms = %llu, rounds = %u, passes = %u\n",
+                     st.ms_pack, st.ms_classify, st.ms_lms_sort, st.ms_place, st.ms_induce, st.ms_total,
+                     (unsigned long long)st.m, st.lms_rounds, st.induce_passes);
+    }
+    if (ctx) kiss_hip_ctx_destroy(ctx);
+    if (!a.output_sa.empty()) {
+        std::ofstream o(a.output_sa, std::ios::binary);
+        o.write(reinterpret_cast<const char *>(SA.data()), (std::streamsize)(SA.size() * 4));
+    }
+    return 0;
+}
+
+int fmindex_build_main(const Args &a)
+{
+    auto S = read_sequence(a.fasta);
+    if (S.empty()) throw std::runtime_error("empty sequence");
+    Fmi f;
+    f.alloc(S.size());
+    check(kiss_hip_fmi_build_host(S.data(), S.size(), nullptr, f.bwt.data(), f.occ1.data(), f.occ2.data(), f.sa.data(),
+                                  f.b.data(), f.b_occ.data(), f.cnt, &f.pri, a.device),
+          "kiss_hip_fmi_build_host");
+    f.save(a.fasta + ".fmi");
+    return 0;
+}
+
+const char *ending(size_t x)
+{
+    x %= 100;
+    if (x / 10 == 1) return "th";
+    if (x % 10 == 1) return "st";
+    if (x % 10 == 2) return "nd";
+    if (x % 10 == 3) return "rd";
+    return "th";
+}
+
+int fmindex_query_main(const Args &a)
+{
+    auto S = read_sequence(a.fasta);
+    Fmi f;
+    f.load(a.fasta + ".fmi");
+    const kiss_hip_fmi_view v = f.view();
+    if (!a.query.empty()) {
+        std::vector<uint8_t> q;
+        for (unsigned char c : a.query) q.push_back(to_code(c));
+        uint32_t beg = 0, end = 0;
+        uint64_t hits = 0, chk = 0;
+        check(kiss_hip_fmi_query_batch_host(&v, q.data(), (uint32_t)q.size(), 1, &beg, &end, &hits, &chk, nullptr, nullptr, 0,
+                                            a.device), "kiss_hip_fmi_query_batch_host");
+        std::vector<uint32_t> off(hits + 1);
+        std::vector<uint64_t> idx(2);
+        if (hits)
+            check(kiss_hip_fmi_query_batch_host(&v, q.data(), (uint32_t)q.size(), 1, &beg, &end, &hits, &chk, off.data(),
+                                                idx.data(), hits, a.device), "kiss_hip_fmi_query_batch_host");
+        std::string qs;
+        for (auto c : q) qs.push_back("ACGT"[c]);
+        std::fprintf(stderr, "[info] query = %s found %llu times\n", qs.c_str(), (unsigned long long)hits);
+        for (size_t i = 0; i < std::min<size_t>(a.headn, hits); i++) {
+            std::string sub;
+            for (size_t j = 0; j < q.size() && off[i] + j < S.size(); j++) sub.push_back("ACGT"[S[off[i] + j]]);
+            std::fprintf(stderr, "[info] The %zu-%s position is %u, content of substring is %s\n", i + 1, ending(i + 1), off[i],
+                         sub.c_str());
+        }
+    }
+    if (!a.batch.empty()) {
+        std::ifstream p(a.batch, std::ios::binary);
+        if (!p) throw std::runtime_error("cannot open " + a.batch);
+        uint32_t L = 0, Q = 0;
+        p.read(reinterpret_cast<char *>(&L), 4);
+        p.read(reinterpret_cast<char *>(&Q), 4);
+        std::fprintf(stderr, "[info] query_len: %u, num_query: %u\n", L, Q);
+        std::vector<uint8_t> pat((size_t)L * Q);
+        p.read(reinterpret_cast<char *>(pat.data()), (std::streamsize)pat.size());
+        if (!p) throw std::runtime_error("truncated pattern file");
+        for (auto &c : pat) c = to_code(c);
+        std::vector<uint32_t> beg(Q), end(Q);
+        uint64_t hits = 0, chk = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        check(kiss_hip_fmi_query_batch_host(&v, pat.data(), L, Q, beg.data(), end.data(), &hits, &chk, nullptr, nullptr, 0,
+                                            a.device), "kiss_hip_fmi_query_batch_host");
+        std::fprintf(stderr, "[info] searching time: %.6f seconds\n", seconds_since(t0));
+        std::fprintf(stderr, "[info] number of matched locations: %llu\n", (unsigned long long)hits);
+        std::fprintf(stderr, "[info] location checksum: %llu\n", (unsigned long long)chk);
+    }
+    return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    try {
+        Args a = parse(argc, argv);
+        // TODO of the reference kept as is: generic alphabets are rejected (suffix_sort.hpp:26-28)
+        if (a.generic) throw std::invalid_argument("Generic sorting and indexing are currently not supported.");
+        if (a.command == "suffix_sort") return suffix_sort_main(a);
+        if (a.command == "fmindex_build") return fmindex_build_main(a);
+        if (a.command == "fmindex_query") return fmindex_query_main(a);
+        usage();
+        throw std::runtime_error("invalid command '" + a.command + "'");
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+}
