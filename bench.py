@@ -39,6 +39,12 @@ ALGO_BYTES = {
 }
 
 
+# HBM traffic measured with rocprofv3 PMC passes (tools/pmc.sh; profiles/r01_pmc_fetch_n5e8.csv and
+# profiles/r01_pmc_write_tcc_n5e8.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads)
+# per algorithmic byte of the same launches: (2 x 4.455e6 KB + 9.379e6 KB) / (5 x 145.4e6 items x 24 B) = 1.05
+MEASURED_TRAFFIC_PER_ALGO_BYTE = {"radix_scatter": 1.05}
+
+
 def gen_text_device(n, seed, device):
     """Genome-like synthetic text on the GPU (torch ops only; deterministic for a given seed).
     Same recipe as tests/gen.py::genome_like (SURVEY.md section 8(d))."""
@@ -244,7 +250,11 @@ def main():
                 avg_s = 1e-3 * a["ms"] / a["launches"]
                 achieved = bytes_per_launch / avg_s / 1e9
                 roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": (bytes_per_launch * MEASURED_TRAFFIC_PER_ALGO_BYTE[name]
+                                    if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
+                        "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
+                                        "kernel (separate rocprofv3 --pmc runs, profiles/r01_pmc_*.csv)",
                         "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / args.steps,
                         "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
                         "kernel_ms_per_step": {kn: kv["ms"] / args.steps for kn, kv in agg.items() if kv["launches"]}}

@@ -1,7 +1,7 @@
 """GPU diagnostics: parity + per-kernel-class timing for selected cases."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kiss_amd
 from tests import gen, oracle_binding
 orc = oracle_binding.load()
