@@ -62,7 +62,33 @@ __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint6
     }
 }
 
-// small segments: final rank of every member by counting, written straight to its final slot;
+// phase A for small segments of >= 3 members: is my successor in the segment not smaller than me?
+// (a segment whose adjacent pairs are all in order is already sorted: the common case for periodic repeats,
+//  where all-pairs ranking would walk s^2 pairs to the full depth)
+__global__ __launch_bounds__(LS_THREADS) void k_seg_adjacent(const uint64_t *__restrict__ pk, uint64_t n,
+                                                            const uint64_t *__restrict__ key,
+                                                            const uint32_t *__restrict__ pos,
+                                                            const uint32_t *__restrict__ seg,
+                                                            const uint32_t *__restrict__ segstart, uint64_t count,
+                                                            uint64_t off, uint64_t depth, uint32_t small_seg,
+                                                            uint8_t *__restrict__ inorder)
+{
+    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t sg = seg[i];
+    const uint32_t a = segstart[sg], b = segstart[sg + 1];
+    const uint32_t len = b - a;
+    if (len < 3 || len > small_seg) return;
+    uint8_t ok = 1;
+    if ((uint32_t)i + 1 < b) {
+        const uint64_t ki = key[i], kn = key[i + 1];
+        if (kn != ki) ok = kn > ki;
+        else ok = !deep_less(pk, n, pos[i + 1], pos[i], off, depth, false);
+    }
+    inorder[i] = ok;
+}
+
+// small segments: final rank of every member, written straight to its final slot;
 // big segments: flagged for the radix path.  big[i] = (1 << 32) | (first item of a big segment)
 __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__restrict__ pk, uint64_t n,
                                                           const uint64_t *__restrict__ key,
@@ -71,6 +97,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           const uint32_t *__restrict__ seg,
                                                           const uint32_t *__restrict__ segstart, uint64_t count,
                                                           uint64_t off, uint64_t depth, uint32_t small_seg,
+                                                          const uint8_t *__restrict__ inorder,
                                                           uint32_t *__restrict__ out, uint64_t *__restrict__ big,
                                                           uint32_t *__restrict__ nbig)
 {
@@ -83,13 +110,22 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
             const uint64_t ki = key[i];
             const uint64_t pi = pos[i];
             uint32_t r = 0;
-            for (uint32_t j = a; j < b; j++) {
-                if (j == (uint32_t)i) continue;
-                uint64_t kj = key[j];
-                bool jless;
-                if (kj != ki) jless = kj < ki;
-                else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i);
-                r += jless ? 1u : 0u;
+            bool sorted = false;
+            if (b - a >= 3) { // adjacent pairs all in order -> already sorted
+                sorted = true;
+                for (uint32_t j = a; j + 1 < b; j++) sorted = sorted && inorder[j];
+            }
+            if (sorted) {
+                r = (uint32_t)i - a;
+            } else {
+                for (uint32_t j = a; j < b; j++) {
+                    if (j == (uint32_t)i) continue;
+                    uint64_t kj = key[j];
+                    bool jless;
+                    if (kj != ki) jless = kj < ki;
+                    else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i);
+                    r += jless ? 1u : 0u;
+                }
             }
             out[slot[a + r]] = (uint32_t)pi;
             big[i] = 0;
@@ -98,8 +134,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
             big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
         }
     }
-    uint64_t bm = __ballot(isbig);
-    if (bm && lane_id() == 0) atomicAdd(nbig, (uint32_t)__popcll(bm));
+    (void)isbig;
+    (void)nbig; // the number of big-segment items comes out of the flag scan (one address hit by every wave's
+                // atomicAdd cost more than the rest of this kernel)
 }
 
 __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__restrict__ key,
@@ -416,35 +453,50 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                K1);
             KCHECK(hipGetLastError());
         }
+        hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;
+        if (dbg) {
+            (void)hipEventCreate(&dbg_e0);
+            (void)hipEventCreate(&dbg_e1);
+            (void)hipEventRecord(dbg_e0, ctx->stream);
+        }
         {
             KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, d_nbig);
+            uint8_t *inorder = reinterpret_cast<uint8_t *>(F2); // F2 is free until the big-segment scan below
+            hipLaunchKernelGGL(k_seg_adjacent, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Gc, SSc, count, off,
+                               depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
-                               count, off, depth, small_seg, ctx->lms_sorted_far, F1, d_nbig);
+                               count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
         ctx->stats.sort_item_rounds += count;
-        uint64_t nbig64 = 0;
-        KTRY(read_u64(ctx, d_nbig, &nbig64));
-        const uint64_t nbig = nbig64 & 0xFFFFFFFFull;
-        if (dbg)
+        // big-segment items and segments: totals of the flag scan
+        KTRY(kiss_scan_u64(ctx, F1, F2, count));
+        hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
+        uint64_t bt;
+        KTRY(read_u64(ctx, d_total, &bt));
+        const uint64_t nbig = bt >> 32;
+        if (dbg) {
+            float ms = 0;
+            (void)hipEventRecord(dbg_e1, ctx->stream);
+            (void)hipEventSynchronize(dbg_e1);
+            (void)hipEventElapsedTime(&ms, dbg_e0, dbg_e1);
+            fprintf(stderr, "[kiss_hip]   seg_finish + flag scan %.3f ms\n", ms);
+            (void)hipEventDestroy(dbg_e0);
+            (void)hipEventDestroy(dbg_e1);
             fprintf(stderr, "[kiss_hip] round off=%llu: items %llu in %llu segments, big-segment items %llu\n",
                     (unsigned long long)off, (unsigned long long)count, (unsigned long long)nseg,
                     (unsigned long long)nbig);
+        }
         if (nbig == 0) break;
         // ---- big segments: compact, radix sort on (segment, key), split, survivors go round again
-        KTRY(kiss_scan_u64(ctx, F1, F2, count));
         {
             KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
             hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, Sc, count, F1, F2,
                                ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot);
-            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
             KCHECK(hipGetLastError());
         }
-        uint64_t bt;
-        KTRY(read_u64(ctx, d_total, &bt));
-        if ((bt >> 32) != nbig) return KINTERNAL();
         const uint64_t nbigseg = bt & 0xFFFFFFFFull;
         RadixBufs bb;
         bb.key[0] = ctx->bkeyA;
