@@ -293,14 +293,23 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
 // Items whose run reaches the cap R continue from the last block in the next call.
 constexpr uint64_t COLLAPSE_N = 1ull << 21;
 constexpr uint32_t COLLAPSE_RCAP = 65535;
+constexpr uint32_t COLLAPSE_RCAP_WIDE = (1u << 22) - 1; // runs of one base longer than 65535: wider steps
 constexpr int CH_THREADS = 256;
 
-__device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, uint64_t v, uint32_t c, uint32_t cap)
+// number of c's right before position v, capped.  Lane-serial for the first RUN_SERIAL bases; a lane whose run is
+// still going after that is served by its whole wave (64 packed words = 2048 bases per coalesced step), so one
+// multi-megabase run of a single base does not serialise on one lane.  Must be called by all lanes of a wave.
+constexpr uint32_t RUN_SERIAL = 1024;
+
+__device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, uint64_t v, uint32_t c, uint32_t cap,
+                                               bool valid)
 {
     const uint64_t pat = (uint64_t)c * 0x5555555555555555ull;
+    const uint32_t scap = cap < RUN_SERIAL ? cap : RUN_SERIAL;
     uint32_t r = 0;
-    uint64_t p = v; // bases before v still to test: indices < p
-    while (p > 0 && r < cap) {
+    uint64_t p = valid ? v : 0; // bases before v still to test: indices < p
+    bool going = false;
+    while (p > 0) {
         const uint64_t q = p - 1;
         const uint32_t in = (uint32_t)(q & 31u) + 1u; // bases of this word with index <= q
         const uint64_t y = (pk[q >> 5] ^ pat) >> (62u - 2u * (uint32_t)(q & 31u)); // base q in bits 1:0, q-1 in 3:2, ...
@@ -309,6 +318,35 @@ __device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, 
         r += mt;
         p -= mt;
         if (mt < in) break;
+        if (r >= scap) {
+            going = r < cap && p > 0; // p is a multiple of 32 here
+            break;
+        }
+    }
+    uint64_t todo = __ballot(going);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        uint64_t lp = __shfl(p, leader, 64);
+        uint32_t lr = __shfl(r, leader, 64);
+        const uint32_t lcap = __shfl(cap, leader, 64);
+        while (true) {
+            const int64_t w = (int64_t)(lp >> 5) - 1 - (int64_t)lane_id();
+            const uint64_t y = w >= 0 ? (pk[w] ^ pat) : 1ull; // before the text: stop, nothing matched
+            const uint64_t stop = __ballot(y != 0);
+            if (!stop) {
+                lr += 2048u;
+                lp -= 2048u;
+                if (lr >= lcap) break;
+                continue;
+            }
+            const int f = __ffsll((unsigned long long)stop) - 1;
+            const uint64_t yf = __shfl(y, f, 64);
+            const bool outside = ((int64_t)(lp >> 5) - 1 - f) < 0;
+            lr += 32u * (uint32_t)f + (outside ? 0u : ((uint32_t)(__ffsll((unsigned long long)yf) - 1) >> 1));
+            break;
+        }
+        if ((int)lane_id() == leader) r = lr;
     }
     return r > cap ? cap : r;
 }
@@ -316,16 +354,16 @@ __device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, 
 // counters: [0..3] terminal items per class, [4] items whose run hit the cap
 __global__ __launch_bounds__(CH_THREADS) void k_chain_runs(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                           int64_t beg, uint64_t N, int dir, uint32_t c, uint32_t cap,
-                                                          uint32_t termmask, uint32_t *__restrict__ run,
+                                                          int rshift, uint32_t termmask, uint32_t *__restrict__ run,
                                                           uint64_t *__restrict__ tkey, uint32_t *__restrict__ tpos,
                                                           uint32_t *__restrict__ counters)
 {
     uint64_t i = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     uint32_t cls = 4u;
     bool capped = false;
+    const uint64_t v = i < N ? srcP[beg + (int64_t)dir * (int64_t)i] : 0;
+    const uint32_t r = run_before(pk, v, c, cap, i < N);
     if (i < N) {
-        const uint64_t v = srcP[beg + (int64_t)dir * (int64_t)i];
-        const uint32_t r = run_before(pk, v, c, cap);
         run[i] = r;
         uint32_t u = 0;
         if (r >= cap) capped = true;
@@ -334,7 +372,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_runs(const uint64_t *__res
             uint32_t x = kiss_base(pk, u);
             if ((termmask >> x) & 1u) cls = x;
         }
-        tkey[i] = cls < 4u ? (((uint64_t)cls << 62) | ((uint64_t)r << 46)) : ~0ull;
+        tkey[i] = cls < 4u ? (((uint64_t)cls << 62) | ((uint64_t)r << rshift)) : ~0ull;
         tpos[i] = u;
     }
 #pragma unroll
@@ -353,7 +391,7 @@ __global__ void k_chain_total(const uint32_t *__restrict__ run, const uint32_t *
 }
 
 __global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *srcP, int64_t beg, int dir, uint64_t N,
-                                                            const uint32_t *__restrict__ ex, uint64_t E,
+                                                            const uint32_t *__restrict__ ex, uint64_t E, int tshift,
                                                             uint64_t *__restrict__ key, uint32_t *__restrict__ pos)
 {
     uint64_t e = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *src
         else hi = mid;
     }
     const uint32_t t = (uint32_t)(e - ex[lo]) + 1u;
-    key[e] = (uint64_t)t << 48;
+    key[e] = (uint64_t)t << tshift;
     pos[e] = srcP[beg + (int64_t)dir * (int64_t)lo] - t;
 }
 
@@ -412,9 +450,13 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
     uint32_t *run = ctx->slotA, *ex = ctx->segA, *tpos = ctx->bposA;
     uint64_t *tkey = ctx->bkeyA;
     uint32_t *counters = ctx->d_small + 16;
+    bool wide = false; // after a call in which runs hit the 16-bit cap: 24-bit step field (one more radix pass)
     while (N > 0) {
-        uint64_t capq = ctx->m_cap / N;
-        uint32_t cap = (uint32_t)(capq > COLLAPSE_RCAP ? COLLAPSE_RCAP : (capq < 1 ? 1 : capq));
+        const uint64_t capq = ctx->m_cap / N;
+        const uint32_t rcap = wide ? COLLAPSE_RCAP_WIDE : COLLAPSE_RCAP;
+        const int tshift = wide ? 40 : 48; // step t in key bits [tshift, 64)
+        const int rshift = tshift - 2;     // terminal key: class in bits 62..63, run in [rshift, 62)
+        uint32_t cap = (uint32_t)(capq > rcap ? rcap : (capq < 1 ? 1 : capq));
         if (const char *e = getenv("KISS_HIP_COLLAPSE_CAP")) { // test hook: force short steps
             uint32_t f = (uint32_t)atoi(e);
             if (f >= 1 && f < cap) cap = f;
@@ -425,7 +467,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
             KTRY(kiss_zero_u32(ctx, counters, 8));
             hipLaunchKernelGGL(k_chain_runs, dim3(grid), dim3(CH_THREADS), 0, ctx->stream, ctx->pk, sw.SA, beg, N, sw.dir,
-                               c, cap, termmask & ~(1u << c), run, tkey, tpos, counters);
+                               c, cap, rshift, termmask & ~(1u << c), run, tkey, tpos, counters);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_scan_u32(ctx, run, ex, N));
@@ -445,7 +487,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         if (E > 0) {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
             hipLaunchKernelGGL(k_chain_expand, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
-                               sw.SA, beg, sw.dir, N, ex, E, ctx->keyA, ctx->posA);
+                               sw.SA, beg, sw.dir, N, ex, E, tshift, ctx->keyA, ctx->posA);
             KCHECK(hipGetLastError());
         }
         if (E > 0) {
@@ -456,7 +498,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             rb.pos[1] = ctx->posB;
             rb.seg[0] = rb.seg[1] = nullptr;
             int res = 0;
-            KTRY(kiss_radix_sort(ctx, rb, E, 48, 0, &res)); // step index t sits in bits 48..63
+            KTRY(kiss_radix_sort(ctx, rb, E, tshift, 0, &res)); // step index t sits in bits tshift..63
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
             hipLaunchKernelGGL(k_chain_write, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
                                ctx->pk, rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
@@ -476,7 +518,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             tb.pos[1] = ctx->bposB;
             tb.seg[0] = tb.seg[1] = nullptr;
             int res = 0;
-            KTRY(kiss_radix_sort(ctx, tb, N, 46, 0, &res)); // (class, run) ; items without a terminal sort last
+            KTRY(kiss_radix_sort(ctx, tb, N, rshift, 0, &res)); // (class, run) ; items without a terminal sort last
             TermDst td;
             uint32_t o = 0;
             for (int x = 0; x < 4; x++) {
@@ -495,6 +537,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         // items whose run reached the cap continue from the last block
         beg = dst + (int64_t)sw.dir * (int64_t)(E - ncap);
         N = ncap;
+        wide = cap >= COLLAPSE_RCAP;
     }
     return KISS_HIP_OK;
 }

@@ -93,3 +93,21 @@ def test_one_shot_entry(oracle):
     assert np.array_equal(sa, oracle.suffix_sort(S, 256))
     sa2 = kiss_amd.KISS2Sorter.get_suffix_array_dna(S, kiss_amd.K_UNBOUNDED)
     assert np.array_equal(sa2, oracle.suffix_sort(S, 0xFFFFFFFF))
+
+
+@pytest.mark.parametrize("k", [256, 0xFFFFFFFF])
+def test_megabase_runs_of_one_base(ctx, oracle, k):
+    # runs longer than the 16-bit and the 22-bit chain-collapse steps (induce.hip run_collapse: narrow, then
+    # wide step fields; run lengths counted by a whole wave past the first 1024 bases)
+    n = 5_500_000
+    S = gen.iid(n, 77)
+    rng = np.random.default_rng(78)
+    S[300_000:300_000 + 4_400_000] = 3            # > 2^22
+    for i, ln in enumerate([70_000, 131_073, 300_000, 65_535, 65_536, 66_000 + 1024, 2048 + 1024, 1024, 1023]):
+        p = 4_750_000 + i * 40_000 if ln < 40_000 else None
+        if p is None:
+            p = int(rng.integers(300_000, 4_000_000))
+        S[p:p + ln] = i % 4
+    check_parity(ctx, oracle, S, k, stages=False)
+    for c in (0, 3):
+        check_parity(ctx, oracle, np.full(n, c, np.uint8), k, stages=False)
