@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--text-len", dest="n", type=int, default=CHM13_N, help="text length (default: chm13v2.0 size)")
     ap.add_argument("--k", type=int, default=256)
+    ap.add_argument("--algo", choices=["parallel_sorting", "prefix_doubling"], default="parallel_sorting",
+                    help="prefix_doubling: exact order (k is ignored), bounded phase + rank doubling")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
     ap.add_argument("--cpu-sample", type=int, default=500_000_000,
@@ -155,6 +157,9 @@ def main():
     device = torch.device("cuda", local_rank)
 
     n, k = args.n, args.k
+    algo = 1 if args.algo == "prefix_doubling" else 0
+    if algo:
+        k = 0xFFFFFFFF
     sharded = (world > 1 and args.mode == "sharded") or args.force_sharded
     seed = args.seed if sharded else args.seed + 1000 * rank  # sharded: every rank holds the same text
     if args.iid:
@@ -177,7 +182,7 @@ def main():
             multi_gpu.sharded_suffix_sort(backend, n, SA=SA if rank == 0 else None)
     else:
         def step():
-            ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, stream=stream)
+            ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo, stream=stream)
 
     for _ in range(args.warmup):
         step()

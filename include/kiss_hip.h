@@ -72,6 +72,12 @@ typedef struct kiss_hip_stats {
     float ms_kernel[16];
     uint64_t launches_kernel[16];
     uint64_t items_kernel[16]; /* units processed (items for radix/induce, bases for classify) */
+    /* PREFIX_DOUBLING (exact order) only: */
+    uint64_t refine_items;    /* suffixes still tied after the bounded-depth phase (depth = refine_depth) */
+    uint32_t refine_depth;    /* bases the bounded phase ordered by (0: doubling phase not used) */
+    uint32_t doubling_rounds; /* rank-doubling rounds executed */
+    float ms_refine;          /* device time of the doubling phase (included in ms_total) */
+    uint32_t reserved_;
 } kiss_hip_stats;
 
 /* kernel classes for ms_kernel[] / launches_kernel[] */

@@ -30,6 +30,8 @@ class Stats(ctypes.Structure):
         ("ms_lms_sort", ctypes.c_float), ("ms_place", ctypes.c_float), ("ms_induce", ctypes.c_float),
         ("ms_kernel", ctypes.c_float * 16), ("launches_kernel", ctypes.c_uint64 * 16),
         ("items_kernel", ctypes.c_uint64 * 16),
+        ("refine_items", ctypes.c_uint64), ("refine_depth", ctypes.c_uint32), ("doubling_rounds", ctypes.c_uint32),
+        ("ms_refine", ctypes.c_float), ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self):

@@ -114,8 +114,24 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         return KISS_HIP_E_UNSUPPORTED;
     }
     ctx->stats.depth = (uint32_t)(depth > 0xFFFFFFFFull ? 0xFFFFFFFFull : depth);
+    // PREFIX_DOUBLING: a bounded-depth phase (order h0, the k-ordered pipeline) followed by rank doubling over
+    // the tied suffixes; texts too short for that go through the unbounded comparison directly.
+    uint32_t h0 = 0;
+    if (algo == KISS_HIP_ALGO_PREFIX_DOUBLING) {
+        h0 = 256;
+        if (const char *e = getenv("KISS_HIP_DOUBLING_H0")) { // tuning hook: 32 <= h0
+            const int v = atoi(e);
+            if (v >= 32 && v <= (1 << 20)) h0 = (uint32_t)v;
+        }
+        if (n < 4ull * h0 + 1024) h0 = 0;
+        else {
+            k = h0;
+            depth = (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
+        }
+    }
+    ctx->stats.refine_depth = h0;
 
-    hipEvent_t ev[6];
+    hipEvent_t ev[7];
     for (auto &e : ev) KCHECK(hipEventCreate(&e));
     int rc = KISS_HIP_OK;
     do {
@@ -130,20 +146,23 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         (void)hipEventRecord(ev[4], ctx->stream);
         if ((rc = kiss_induce(ctx, n, d_SA))) break;
         (void)hipEventRecord(ev[5], ctx->stream);
+        if (h0 && (rc = kiss_exact_refine(ctx, n, h0, d_SA))) break;
+        (void)hipEventRecord(ev[6], ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             ctx->last_hip_error = (int)e;
             rc = KISS_HIP_E_HIP;
             break;
         }
-        float ms[5];
-        for (int i = 0; i < 5; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+        float ms[6];
+        for (int i = 0; i < 6; i++) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+        ctx->stats.ms_refine = h0 ? ms[5] : 0.f;
         ctx->stats.ms_pack = ms[0];
         ctx->stats.ms_classify = ms[1];
         ctx->stats.ms_lms_sort = ms[2];
         ctx->stats.ms_place = ms[3];
         ctx->stats.ms_induce = ms[4];
-        (void)hipEventElapsedTime(&ctx->stats.ms_total, ev[0], ev[5]);
+        (void)hipEventElapsedTime(&ctx->stats.ms_total, ev[0], ev[6]);
     } while (0);
     if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
     ctx->stats.m = ctx->m;

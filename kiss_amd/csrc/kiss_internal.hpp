@@ -120,6 +120,8 @@ struct RadixBufs {
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
 // k-ordered LMS sort of the far suffixes -> ctx->lms_sorted_far
 int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
+// exact order from an h0-ordered SA by rank doubling over the full suffix array (lms_sort.hip)
+int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // induced sort sweeps -> d_SA

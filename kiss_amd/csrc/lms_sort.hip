@@ -211,21 +211,33 @@ constexpr int FC_THREADS = 256;
 constexpr int FC_ITEMS = 8;
 constexpr int FC_TILE = FC_THREADS * FC_ITEMS;
 
-template <bool HAS_SEG>
+// where a segment starts: FC_KEY = the key changes, FC_KEY_SEG = the key or the segment id changes,
+// FC_HEADS = `key` points at one byte per item (1 = starts a segment)
+constexpr int FC_KEY = 0, FC_KEY_SEG = 1, FC_HEADS = 2;
+
+template <int SRC>
 __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const uint32_t *__restrict__ seg, uint64_t i,
                                          uint64_t count, int cmp_shift, int last_round, bool &surv, bool &shead)
 {
     surv = shead = false;
     if (i >= count) return;
-    uint64_t k = key[i] >> cmp_shift;
-    uint32_t s = HAS_SEG ? seg[i] : 0u;
-    bool head = (i == 0) || (key[i - 1] >> cmp_shift) != k || (HAS_SEG && seg[i - 1] != s);
-    bool nhead = (i + 1 == count) || (key[i + 1] >> cmp_shift) != k || (HAS_SEG && seg[i + 1] != s);
+    bool head, nhead;
+    if constexpr (SRC == FC_HEADS) {
+        const uint8_t *hb = reinterpret_cast<const uint8_t *>(key);
+        head = (i == 0) || hb[i] != 0;
+        nhead = (i + 1 == count) || hb[i + 1] != 0;
+    } else {
+        constexpr bool HAS_SEG = SRC == FC_KEY_SEG;
+        uint64_t k = key[i] >> cmp_shift;
+        uint32_t s = HAS_SEG ? seg[i] : 0u;
+        head = (i == 0) || (key[i - 1] >> cmp_shift) != k || (HAS_SEG && seg[i - 1] != s);
+        nhead = (i + 1 == count) || (key[i + 1] >> cmp_shift) != k || (HAS_SEG && seg[i + 1] != s);
+    }
     surv = !(head && nhead) && !last_round;
     shead = surv && head;
 }
 
-template <bool HAS_SEG>
+template <int SRC>
 __global__ __launch_bounds__(FC_THREADS) void k_fc_count(const uint64_t *__restrict__ key,
                                                         const uint32_t *__restrict__ seg, uint64_t count,
                                                         int cmp_shift, int last_round, uint64_t *__restrict__ tcnt)
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_count(const uint64_t *__restr
 #pragma unroll
     for (int j = 0; j < FC_ITEMS; j++) {
         bool sv, sh;
-        fc_flags<HAS_SEG>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
+        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
         ns += (uint32_t)__popcll(__ballot(sv));
         nh += (uint32_t)__popcll(__ballot(sh));
     }
@@ -256,7 +268,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_count(const uint64_t *__restr
     }
 }
 
-template <bool HAS_SEG, bool HAS_SLOT>
+// out: retired items land in out[slot] (nullptr: they already are where they belong);
+// isa (optional): inverse array, isa[position] = slot for every retired item
+template <int SRC, bool HAS_SLOT>
 __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__restrict__ key,
                                                           const uint32_t *__restrict__ seg,
                                                           const uint32_t *__restrict__ pos,
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           const uint64_t *__restrict__ tex, // exclusive scan of tcnt
                                                           uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
                                                           uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
-                                                          uint32_t *__restrict__ out)
+                                                          uint32_t *__restrict__ out, uint32_t *__restrict__ isa)
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
 #pragma unroll
     for (int j = 0; j < FC_ITEMS; j++) {
         bool sv, sh;
-        fc_flags<HAS_SEG>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
+        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
         const uint64_t ms = __ballot(sv), mh = __ballot(sh);
         rs[j] = ns + (uint32_t)__popcll(ms & lanemask_lt());
         rh[j] = nh + (uint32_t)__popcll(mh & lanemask_lt()) + (sh ? 1u : 0u);
@@ -309,7 +323,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             nseg[ni] = sid;
             if ((fl >> (2 * j)) & 2u) nsegstart[sid] = ni;
         } else {
-            out[sl] = p;
+            if (out) out[sl] = p;
+            if (isa) isa[p] = sl;
         }
     }
 }
@@ -320,33 +335,59 @@ __global__ void k_fc_total(const uint64_t *__restrict__ tcnt, const uint64_t *__
     if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = tex[tiles - 1] + tcnt[tiles - 1];
 }
 
-// flag + compact of `count` sorted items; on return *tot = (survivors << 32) | surviving segments
+// flag + compact of `count` sorted items, in two halves so a caller can size buffers in between:
+// fc_count + fc_read_total: (survivors << 32) | surviving segments;  fc_compact: the data movement
+template <int SRC>
+int fc_count(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, uint64_t count, int cmp_shift, int last_round,
+             uint64_t *d_total)
+{
+    const uint64_t tiles = div_up(count, FC_TILE);
+    if (2 * tiles > 2 * ctx->m_cap) return KINTERNAL();
+    uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles; // 2 * tiles u64 <= 2 * m_cap
+    {
+        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+        hipLaunchKernelGGL((k_fc_count<SRC>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
+                           cmp_shift, last_round, tcnt);
+        KCHECK(hipGetLastError());
+    }
+    KTRY(kiss_scan_u64(ctx, tcnt, tex, tiles));
+    hipLaunchKernelGGL(k_fc_total, dim3(1), dim3(64), 0, ctx->stream, tcnt, tex, tiles, d_total);
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}
+
+int fc_read_total(kiss_hip_ctx *ctx, const uint64_t *d_total, uint64_t *tot)
+{
+    KCHECK(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(tot, ctx->h_pinned, sizeof(uint64_t));
+    return KISS_HIP_OK;
+}
+
+template <int SRC, bool HAS_SLOT>
+int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
+               uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
+               uint32_t *nsegstart, uint32_t *out, uint32_t *isa)
+{
+    const uint64_t tiles = div_up(count, FC_TILE);
+    const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
+    KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+    hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
+                       pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa);
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}
+
 template <bool HAS_SEG, bool HAS_SLOT>
 int fused_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                   uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
                   uint32_t *nsegstart, uint64_t *d_total, uint64_t *tot)
 {
-    const uint64_t tiles = div_up(count, FC_TILE);
-    uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles; // 2 * tiles u64 << 2 * m_cap
-    {
-        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_fc_count<HAS_SEG>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
-                           cmp_shift, last_round, tcnt);
-        KCHECK(hipGetLastError());
-    }
-    KTRY(kiss_scan_u64(ctx, tcnt, tex, tiles));
-    {
-        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_fc_compact<HAS_SEG, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key,
-                           seg, pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
-                           ctx->lms_sorted_far);
-        hipLaunchKernelGGL(k_fc_total, dim3(1), dim3(64), 0, ctx->stream, tcnt, tex, tiles, d_total);
-        KCHECK(hipGetLastError());
-    }
-    KCHECK(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
-    std::memcpy(tot, ctx->h_pinned, sizeof(uint64_t));
-    return KISS_HIP_OK;
+    constexpr int SRC = HAS_SEG ? FC_KEY_SEG : FC_KEY;
+    KTRY((fc_count<SRC>(ctx, key, seg, count, cmp_shift, last_round, d_total)));
+    KTRY((fc_compact<SRC, HAS_SLOT>(ctx, key, seg, pos, slot, count, cmp_shift, last_round, npos, nslot, nseg, nsegstart,
+                                    ctx->lms_sorted_far, nullptr)));
+    return fc_read_total(ctx, d_total, tot);
 }
 
 __global__ void k_last_total(const uint64_t *__restrict__ flags, const uint64_t *__restrict__ ex, uint64_t count,
@@ -516,4 +557,188 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         if (!depth && off > n + 64 && count > 0) return KINTERNAL(); // exact mode must have terminated
     }
     return KISS_HIP_OK;
+}
+
+// =============================================================================================================
+// Exact order by prefix doubling (the KISS2 / PREFIX_DOUBLING path, reference kiss2_core.hpp:728-797: sort,
+// re-rank, compact, double).  The reference doubles over an encoded LMS string; here the doubling runs over
+// the full suffix array, which 288 GB of HBM affords and which needs no sampled-rank bookkeeping:
+//   1. the k-ordered pipeline has produced SA ordered by the first h0 bases (ties in arbitrary order);
+//   2. group heads: SA[i] starts a group unless it shares h0 bases with SA[i-1]          (k_group_heads)
+//   3. ISA[SA[i]] = i, then for tied suffixes the slot of their group head                 (k_isa_init/update)
+//   4. rounds h = h0, 2*h0, ...: every tied suffix p fetches ISA[p + h], groups are radix sorted on
+//      (group, rank), split where neighbours differ; singletons retire to SA, the rest get new ranks.
+// Only the *result* (the unique suffix array) is comparable with the reference; the number of rounds is
+// O(log(longest repeat / h0)) instead of the MSD path's O(longest repeat / 32).
+// =============================================================================================================
+namespace {
+
+__global__ __launch_bounds__(LS_THREADS) void k_group_heads(const uint64_t *__restrict__ pk, uint64_t n,
+                                                           const uint32_t *__restrict__ SA, uint64_t count, uint32_t h0,
+                                                           uint8_t *__restrict__ heads)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    const bool valid = i < count;
+    const uint64_t p = valid ? SA[i] : 0;
+    const bool pfull = valid && p + h0 <= n;
+    const uint64_t kp = pfull ? kiss_key32(pk, p) : 0ull; // h0 >= 32
+    // predecessor's first word: from the neighbouring lane, lane 0 loads it
+    uint64_t q = __shfl_up(p, 1, 64);
+    uint64_t kq = __shfl_up(kp, 1, 64);
+    bool qfull = __shfl_up((int)pfull, 1, 64) != 0;
+    if (lane_id() == 0 && valid && i > 0) {
+        q = SA[i - 1];
+        qfull = q + h0 <= n;
+        kq = qfull ? kiss_key32(pk, q) : 0ull;
+    }
+    if (!valid) return;
+    uint8_t head = 1;
+    if (i > 0 && pfull && qfull && kp == kq) {
+        head = 0;
+        for (uint32_t d = 32; d < h0; d += 32) {
+            uint64_t a = kiss_key32(pk, p + d), b = kiss_key32(pk, q + d);
+            if (h0 - d < 32) {
+                const uint64_t mask = ~0ull << (64 - 2 * (h0 - d));
+                a &= mask;
+                b &= mask;
+            }
+            if (a != b) {
+                head = 1;
+                break;
+            }
+        }
+    }
+    heads[i] = head;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_isa_init(const uint32_t *__restrict__ SA, uint64_t count,
+                                                        uint32_t *__restrict__ isa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i < count) isa[SA[i]] = (uint32_t)i;
+}
+
+// rank of a tied suffix = slot of the first member of its group
+__global__ __launch_bounds__(LS_THREADS) void k_isa_update(const uint32_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ slot,
+                                                          const uint32_t *__restrict__ seg,
+                                                          const uint32_t *__restrict__ segstart, uint64_t count,
+                                                          uint32_t *__restrict__ isa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i < count) isa[pos[i]] = slot[segstart[seg[i]]];
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_gather_ranks(const uint32_t *__restrict__ isa,
+                                                            const uint32_t *__restrict__ pos, uint64_t count, uint64_t h,
+                                                            uint64_t n, uint64_t *__restrict__ key)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    uint64_t q = (uint64_t)pos[i] + h;
+    if (q > n) q = n; // cannot happen for a tied suffix (it shares h bases with another one); isa[n] = 0
+    key[i] = (uint64_t)isa[q] << 32;
+}
+
+} // namespace
+
+int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA)
+{
+    if (h0 < 32 || n < h0) return KINTERNAL();
+    const uint64_t total = n + 1;
+    const unsigned T = LS_THREADS;
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    uint32_t *isa = ctx->CTX; // the induction's context words are dead by now: (n + 2) u32
+    uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
+    uint8_t *heads = nullptr;
+    KCHECK(hipMalloc((void **)&heads, total));
+    int rc = KISS_HIP_OK;
+    do {
+        {
+            KTimer t(ctx, KISS_HIP_K_SEGRANK, total);
+            hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
+                               total, h0, heads);
+            hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
+        }
+        uint64_t tot;
+        if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
+        if ((rc = fc_read_total(ctx, d_total, &tot))) break;
+        uint64_t count = tot >> 32, nseg = tot & 0xFFFFFFFFull;
+        ctx->stats.refine_items = count;
+        if (dbg)
+            fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffixes tied at depth %u in %llu groups\n",
+                    (unsigned long long)count, (unsigned long long)total, h0, (unsigned long long)nseg);
+        if (count == 0) break;
+        if (count > ctx->m_cap) { // regrow the LMS-side work buffers (their contents are dead); keeps CTX and pk
+            const uint64_t tiles = div_up(total, FC_TILE);
+            uint64_t want = count + count / 64 + 1024;
+            if (want < tiles) want = tiles;
+            if ((rc = kiss_lms_reserve(ctx, want))) break;
+            if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
+        }
+        uint32_t *P = ctx->posA, *P2 = ctx->posB;
+        uint32_t *S = ctx->slotA, *S2 = ctx->slotB;
+        uint32_t *G = ctx->segA, *G2 = ctx->segB;
+        uint32_t *SS = ctx->segstartA, *SS2 = ctx->segstartB;
+        if ((rc = fc_compact<FC_HEADS, false>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, d_SA, nullptr, total, 0,
+                                              0, P, S, G, SS, nullptr, nullptr)))
+            break;
+        {
+            KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+            hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS, count,
+                               isa);
+        }
+        uint64_t h = h0;
+        while (count > 0) {
+            if (h > 2 * n + 64) {
+                rc = KINTERNAL();
+                break;
+            }
+            const unsigned grid = (unsigned)div_up(count, T);
+            {
+                KTimer t(ctx, KISS_HIP_K_KEYGATHER, count);
+                hipLaunchKernelGGL(k_gather_ranks, dim3(grid), dim3(T), 0, ctx->stream, isa, P, count, h, n, ctx->bkeyA);
+            }
+            RadixBufs bb;
+            bb.key[0] = ctx->bkeyA;
+            bb.key[1] = ctx->bkeyB;
+            bb.pos[0] = P;
+            bb.pos[1] = ctx->bposB;
+            bb.seg[0] = G;
+            bb.seg[1] = ctx->bsegB;
+            int bres = 0;
+            if ((rc = kiss_radix_sort(ctx, bb, count, 32, bits_for(nseg), &bres))) break;
+            ctx->stats.doubling_rounds++;
+            ctx->stats.big_item_rounds += count;
+            if ((rc = fc_count<FC_KEY_SEG>(ctx, bb.key[bres], bb.seg[bres], count, 32, 0, d_total))) break;
+            // singletons retire into SA and ISA; survivors are compacted (slots stay in index order)
+            if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, bb.key[bres], bb.seg[bres], bb.pos[bres], S, count, 32, 0, P2, S2, G2,
+                                                   SS2, d_SA, isa)))
+                break;
+            if ((rc = fc_read_total(ctx, d_total, &tot))) break;
+            const uint64_t ncount = tot >> 32;
+            nseg = tot & 0xFFFFFFFFull;
+            if (dbg)
+                fprintf(stderr, "[kiss_hip] refine h=%llu: items %llu -> %llu in %llu groups\n", (unsigned long long)h,
+                        (unsigned long long)count, (unsigned long long)ncount, (unsigned long long)nseg);
+            count = ncount;
+            std::swap(P, P2);
+            std::swap(S, S2);
+            std::swap(G, G2);
+            std::swap(SS, SS2);
+            if (count) {
+                KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+                hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS,
+                                   count, isa);
+            }
+            h *= 2;
+        }
+    } while (0);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (rc == KISS_HIP_OK && e != hipSuccess) {
+        ctx->last_hip_error = (int)e;
+        rc = KISS_HIP_E_HIP;
+    }
+    (void)hipFree(heads);
+    return rc;
 }

@@ -111,3 +111,64 @@ def test_megabase_runs_of_one_base(ctx, oracle, k):
     check_parity(ctx, oracle, S, k, stages=False)
     for c in (0, 3):
         check_parity(ctx, oracle, np.full(n, c, np.uint8), k, stages=False)
+
+
+def _exact_by_doubling(ctx, oracle, S, h0=None, monkeypatch=None):
+    import kiss_amd
+    S = np.ascontiguousarray(S, dtype=np.uint8)
+    sa = ctx.suffix_sort(S, kiss_amd.K_UNBOUNDED, algo=1)
+    ref = oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED)
+    if not np.array_equal(sa, ref):
+        bad = np.nonzero(sa != ref)[0]
+        raise AssertionError("doubling SA differs at %d of %d entries, first at %d: gpu %d ref %d (stats %s)"
+                             % (bad.size, sa.size, bad[0], sa[bad[0]], ref[bad[0]],
+                                {k: v for k, v in ctx.stats().items() if k != "kernels"}))
+    return ctx.stats()
+
+
+@pytest.mark.parametrize("shape", ["iid", "genome", "period1", "period2", "period7", "period400", "period5000",
+                                   "runs", "nested", "tail_repeat"])
+def test_prefix_doubling_exact(ctx, oracle, shape):
+    # KISS2 / PREFIX_DOUBLING path (reference kiss2_core.hpp:835-886): bounded phase + rank doubling over the
+    # full suffix array; the result is the unique exact suffix array, also on texts whose repeats are as long as
+    # the text (where comparing 32 bases per round would need n/32 rounds)
+    n = 300_000
+    rng = np.random.default_rng(11)
+    if shape == "iid":
+        S = gen.iid(n, 3)
+    elif shape == "genome":
+        S = gen.genome_like(n, 4)
+    elif shape.startswith("period"):
+        p = int(shape[6:])
+        S = np.tile(rng.integers(0, 4, p, dtype=np.uint8), n // p + 1)[:n]
+        if p == 400:
+            S = S.copy()
+            S[rng.integers(0, n, 5)] = 1  # a few mutations
+    elif shape == "runs":
+        S = gen.iid(n, 5)
+        for i in range(40):
+            a = int(rng.integers(0, n - 9000))
+            S[a:a + int(rng.integers(300, 9000))] = i % 4
+    elif shape == "nested":
+        u = rng.integers(0, 4, 700, dtype=np.uint8)
+        S = np.concatenate([u, u, u[:350], gen.iid(5000, 6), u, u, u, u, gen.iid(n - 5000 - 700 * 6 - 350, 7)])
+    else:  # the text ends inside a long copy of its own beginning
+        base = gen.iid(n // 2, 8)
+        S = np.concatenate([base, gen.iid(100, 9), base[:n // 2 - 100 - 37]])
+    st = _exact_by_doubling(ctx, oracle, S)
+    assert st["refine_depth"] == 256
+    if shape in ("period1", "period2", "period7", "period400", "period5000", "nested", "tail_repeat"):
+        assert st["doubling_rounds"] >= 1 and st["refine_items"] > 0
+        assert st["doubling_rounds"] <= 14  # log2(n / 256) + slack, not n / 32
+
+
+def test_prefix_doubling_small_and_depths(ctx, oracle, monkeypatch):
+    import kiss_amd
+    for n in [0, 1, 2, 31, 300, 1024, 2047, 2048, 2049, 5000]:
+        S = gen.periodic(n, 3, 1, mutations=2) if n > 10 else gen.iid(n, n)
+        _exact_by_doubling(ctx, oracle, S)
+    S = gen.periodic(60_000, 37, 2, mutations=3)
+    for h0 in ("32", "33", "64", "124", "125", "1000"):
+        monkeypatch.setenv("KISS_HIP_DOUBLING_H0", h0)
+        st = _exact_by_doubling(ctx, oracle, S)
+        assert st["refine_depth"] == int(h0)
