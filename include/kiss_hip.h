@@ -96,7 +96,9 @@ enum {
     KISS_HIP_K_FM_QUERY = 11,
     KISS_HIP_K_FM_BUILD = 12,
     KISS_HIP_K_SEGRANK = 13,
-    KISS_HIP_K_NCLASSES = 14
+    KISS_HIP_K_GROUP_HEADS = 14, /* PREFIX_DOUBLING: tie detection over the bounded-depth SA */
+    KISS_HIP_K_ISA = 15,         /* PREFIX_DOUBLING: inverse suffix array init / rank updates */
+    KISS_HIP_K_NCLASSES = 16
 };
 
 int kiss_hip_version(void);

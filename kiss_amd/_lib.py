@@ -18,6 +18,7 @@ MAX_N = 4294967276
 KERNEL_CLASSES = [
     "pack", "classify", "radix_hist", "radix_scatter", "scan", "keygather", "flag_compact",
     "place", "induce_count", "induce_scatter", "induce_small", "fm_query", "fm_build", "segrank",
+    "group_heads", "isa",
 ]
 
 

@@ -618,15 +618,76 @@ __global__ __launch_bounds__(LS_THREADS) void k_isa_init(const uint32_t *__restr
     if (i < count) isa[SA[i]] = (uint32_t)i;
 }
 
+// inverse of a permutation without random HBM writes: (position, index) pairs are binned on the top 8 bits of
+// the position (one stable radix pass), so the final scatter walks the inverse array window by window
+// (2^24 entries = 64 MiB, which the 256 MiB last-level cache absorbs)
+__global__ __launch_bounds__(LS_THREADS) void k_isa_pairs(const uint32_t *__restrict__ SA, uint64_t base, uint64_t count,
+                                                         uint64_t *__restrict__ key)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i < count) key[i] = ((uint64_t)SA[base + i] << 32) | (base + i);
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_isa_from_pairs(const uint64_t *__restrict__ key, uint64_t count,
+                                                              uint32_t *__restrict__ isa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i < count) {
+        const uint64_t k = key[i];
+        isa[k >> 32] = (uint32_t)k;
+    }
+}
+
 // rank of a tied suffix = slot of the first member of its group
+// (also reports the longest group: *maxlen, zeroed by the caller; segstart[nseg] = count)
 __global__ __launch_bounds__(LS_THREADS) void k_isa_update(const uint32_t *__restrict__ pos,
                                                           const uint32_t *__restrict__ slot,
                                                           const uint32_t *__restrict__ seg,
                                                           const uint32_t *__restrict__ segstart, uint64_t count,
-                                                          uint32_t *__restrict__ isa)
+                                                          uint32_t *__restrict__ isa, uint32_t *__restrict__ maxlen)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i < count) isa[pos[i]] = slot[segstart[seg[i]]];
+    uint32_t len = 0;
+    if (i < count) {
+        const uint32_t sg = seg[i];
+        const uint32_t a = segstart[sg];
+        isa[pos[i]] = slot[a];
+        if ((uint32_t)i == a) len = segstart[sg + 1] - a;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(len, d, 64);
+        len = o > len ? o : len;
+    }
+    if (lane_id() == 0 && len > 64) atomicMax(maxlen, len); // only groups past the in-wave sort size matter
+}
+
+// groups of <= 64 members: every member ranks itself inside its group on (key, index) and moves there;
+// the group ids stay where they are (all members of a group carry the same one)
+__global__ __launch_bounds__(LS_THREADS) void k_group_sort_small(const uint64_t *__restrict__ key,
+                                                                const uint32_t *__restrict__ pos,
+                                                                const uint32_t *__restrict__ seg,
+                                                                const uint32_t *__restrict__ segstart, uint64_t count,
+                                                                uint64_t *__restrict__ okey, uint32_t *__restrict__ opos,
+                                                                uint64_t *__restrict__ big)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t sg = seg[i];
+    const uint32_t a = segstart[sg], b = segstart[sg + 1];
+    if (big) { // longer groups exist: flag their members for the radix path, (1 << 32) | starts-a-group
+        const bool isbig = b - a > SMALL_SEG;
+        big[i] = isbig ? ((1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u)) : 0ull;
+        if (isbig) return;
+    }
+    const uint64_t ki = key[i];
+    uint32_t r = 0;
+    for (uint32_t j = a; j < b; j++) {
+        const uint64_t kj = key[j];
+        r += (kj < ki || (kj == ki && j < (uint32_t)i)) ? 1u : 0u;
+    }
+    okey[a + r] = ki;
+    opos[a + r] = pos[i];
 }
 
 __global__ __launch_bounds__(LS_THREADS) void k_gather_ranks(const uint32_t *__restrict__ isa,
@@ -638,6 +699,39 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_ranks(const uint32_t *__r
     uint64_t q = (uint64_t)pos[i] + h;
     if (q > n) q = n; // cannot happen for a tied suffix (it shares h bases with another one); isa[n] = 0
     key[i] = (uint64_t)isa[q] << 32;
+}
+
+// members of long groups -> compact arrays (dense group ids), remembering where they came from
+__global__ __launch_bounds__(LS_THREADS) void k_big_extract(const uint64_t *__restrict__ key,
+                                                           const uint32_t *__restrict__ pos, uint64_t count,
+                                                           const uint64_t *__restrict__ big,
+                                                           const uint64_t *__restrict__ ex, uint64_t *__restrict__ bkey,
+                                                           uint32_t *__restrict__ bpos, uint32_t *__restrict__ bseg,
+                                                           uint32_t *__restrict__ bidx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t f = big[i];
+    if (!(f >> 32)) return;
+    const uint64_t e = ex[i];
+    const uint32_t kx = (uint32_t)(e >> 32);
+    bkey[kx] = key[i];
+    bpos[kx] = pos[i];
+    bseg[kx] = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
+    bidx[kx] = (uint32_t)i;
+}
+
+// sorted on (group, key): the c-th item goes back to where the c-th extracted item came from
+__global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__restrict__ skey,
+                                                             const uint32_t *__restrict__ spos,
+                                                             const uint32_t *__restrict__ bidx, uint64_t nbig,
+                                                             uint64_t *__restrict__ okey, uint32_t *__restrict__ opos)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (c >= nbig) return;
+    const uint32_t i = bidx[c];
+    okey[i] = skey[c];
+    opos[i] = spos[c];
 }
 
 } // namespace
@@ -655,10 +749,47 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     int rc = KISS_HIP_OK;
     do {
         {
-            KTimer t(ctx, KISS_HIP_K_SEGRANK, total);
+            KTimer t(ctx, KISS_HIP_K_GROUP_HEADS, total);
             hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
                                total, h0, heads);
+        }
+        if (total <= (1ull << 26) || getenv("KISS_HIP_ISA_DIRECT")) { // the whole inverse array is cache resident
+            KTimer t(ctx, KISS_HIP_K_ISA, total);
             hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
+        } else {
+            uint64_t chunk = ctx->m_cap;
+            void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (getenv("KISS_HIP_ISA_ONECHUNK")) { // experiment
+                chunk = total;
+                KCHECK(hipMalloc(&tmp[0], total * 8));
+                KCHECK(hipMalloc(&tmp[1], total * 8));
+                KCHECK(hipMalloc(&tmp[2], total * 4));
+                KCHECK(hipMalloc(&tmp[3], total * 4));
+            }
+            for (uint64_t base = 0; base < total && rc == KISS_HIP_OK; base += chunk) {
+                const uint64_t cnt = total - base < chunk ? total - base : chunk;
+                RadixBufs rb;
+                rb.key[0] = tmp[0] ? (uint64_t *)tmp[0] : ctx->keyA;
+                rb.key[1] = tmp[0] ? (uint64_t *)tmp[1] : ctx->keyB;
+                rb.pos[0] = tmp[0] ? (uint32_t *)tmp[2] : ctx->posA; // payload not used here
+                rb.pos[1] = tmp[0] ? (uint32_t *)tmp[3] : ctx->posB;
+                rb.seg[0] = rb.seg[1] = nullptr;
+                {
+                    KTimer t(ctx, KISS_HIP_K_ISA, cnt);
+                    hipLaunchKernelGGL(k_isa_pairs, dim3((unsigned)div_up(cnt, T)), dim3(T), 0, ctx->stream, d_SA, base, cnt,
+                                       rb.key[0]);
+                }
+                int res = 0;
+                if ((rc = kiss_radix_sort(ctx, rb, cnt, 56, 0, &res))) break;
+                KTimer t(ctx, KISS_HIP_K_ISA, cnt);
+                hipLaunchKernelGGL(k_isa_from_pairs, dim3((unsigned)div_up(cnt, T)), dim3(T), 0, ctx->stream, rb.key[res],
+                                   cnt, isa);
+            }
+            if (tmp[0]) {
+                (void)hipStreamSynchronize(ctx->stream);
+                for (auto &t : tmp) (void)hipFree(t);
+            }
+            if (rc) break;
         }
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
@@ -683,10 +814,12 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
         if ((rc = fc_compact<FC_HEADS, false>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, d_SA, nullptr, total, 0,
                                               0, P, S, G, SS, nullptr, nullptr)))
             break;
+        uint32_t *d_maxlen = ctx->d_small + 8;
         {
-            KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+            KTimer t(ctx, KISS_HIP_K_ISA, count);
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, d_maxlen);
             hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS, count,
-                               isa);
+                               isa, d_maxlen);
         }
         uint64_t h = h0;
         while (count > 0) {
@@ -699,37 +832,67 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 KTimer t(ctx, KISS_HIP_K_KEYGATHER, count);
                 hipLaunchKernelGGL(k_gather_ranks, dim3(grid), dim3(T), 0, ctx->stream, isa, P, count, h, n, ctx->bkeyA);
             }
-            RadixBufs bb;
-            bb.key[0] = ctx->bkeyA;
-            bb.key[1] = ctx->bkeyB;
-            bb.pos[0] = P;
-            bb.pos[1] = ctx->bposB;
-            bb.seg[0] = G;
-            bb.seg[1] = ctx->bsegB;
-            int bres = 0;
-            if ((rc = kiss_radix_sort(ctx, bb, count, 32, bits_for(nseg), &bres))) break;
+            uint64_t ml;
+            if ((rc = read_u64(ctx, d_maxlen, &ml))) break; // longest group (0: none longer than 64)
+            const uint32_t maxlen = (uint32_t)ml;
+            // groups of <= 64 sort themselves in place; members of longer groups are pulled out, radix sorted on
+            // (group, rank) and put back -- sorted keys in bkeyB, positions in bposB, group ids unchanged in G
+            uint64_t *F1 = ctx->flags, *F2 = ctx->flags + ctx->m_cap;
+            {
+                KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+                hipLaunchKernelGGL(k_group_sort_small, dim3(grid), dim3(T), 0, ctx->stream, ctx->bkeyA, P, G, SS, count,
+                                   ctx->bkeyB, ctx->bposB, maxlen > SMALL_SEG ? F1 : nullptr);
+            }
+            if (maxlen > SMALL_SEG) {
+                if ((rc = kiss_scan_u64(ctx, F1, F2, count))) break;
+                hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
+                uint64_t bt;
+                if ((rc = read_u64(ctx, d_total, &bt))) break;
+                const uint64_t nbig = bt >> 32, nbigseg = bt & 0xFFFFFFFFull;
+                RadixBufs bb;
+                bb.key[0] = ctx->keyA;
+                bb.key[1] = ctx->keyB;
+                bb.pos[0] = ctx->lmsP;
+                bb.pos[1] = ctx->lmsC;
+                bb.seg[0] = ctx->bsegA;
+                bb.seg[1] = ctx->bsegB;
+                uint32_t *bidx = ctx->bposA;
+                {
+                    KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+                    hipLaunchKernelGGL(k_big_extract, dim3(grid), dim3(T), 0, ctx->stream, ctx->bkeyA, P, count, F1, F2,
+                                       bb.key[0], bb.pos[0], bb.seg[0], bidx);
+                }
+                int bres = 0;
+                if ((rc = kiss_radix_sort(ctx, bb, nbig, 32, bits_for(nbigseg), &bres))) break;
+                ctx->stats.big_item_rounds += nbig;
+                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+                hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)div_up(nbig, T)), dim3(T), 0, ctx->stream, bb.key[bres],
+                                   bb.pos[bres], bidx, nbig, ctx->bkeyB, ctx->bposB);
+            }
+            const uint64_t *skey = ctx->bkeyB;
+            const uint32_t *spos = ctx->bposB, *sseg = G;
             ctx->stats.doubling_rounds++;
-            ctx->stats.big_item_rounds += count;
-            if ((rc = fc_count<FC_KEY_SEG>(ctx, bb.key[bres], bb.seg[bres], count, 32, 0, d_total))) break;
+            ctx->stats.sort_item_rounds += count;
+            if ((rc = fc_count<FC_KEY_SEG>(ctx, skey, sseg, count, 32, 0, d_total))) break;
             // singletons retire into SA and ISA; survivors are compacted (slots stay in index order)
-            if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, bb.key[bres], bb.seg[bres], bb.pos[bres], S, count, 32, 0, P2, S2, G2,
-                                                   SS2, d_SA, isa)))
-                break;
+            if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, skey, sseg, spos, S, count, 32, 0, P2, S2, G2, SS2, d_SA, isa))) break;
             if ((rc = fc_read_total(ctx, d_total, &tot))) break;
             const uint64_t ncount = tot >> 32;
             nseg = tot & 0xFFFFFFFFull;
             if (dbg)
-                fprintf(stderr, "[kiss_hip] refine h=%llu: items %llu -> %llu in %llu groups\n", (unsigned long long)h,
-                        (unsigned long long)count, (unsigned long long)ncount, (unsigned long long)nseg);
+                fprintf(stderr, "[kiss_hip] refine h=%llu: items %llu (longest group %s%u) -> %llu in %llu groups\n",
+                        (unsigned long long)h, (unsigned long long)count, maxlen ? "" : "<= ", maxlen ? maxlen : 64u,
+                        (unsigned long long)ncount, (unsigned long long)nseg);
             count = ncount;
             std::swap(P, P2);
             std::swap(S, S2);
             std::swap(G, G2);
             std::swap(SS, SS2);
             if (count) {
-                KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+                KTimer t(ctx, KISS_HIP_K_ISA, count);
+                hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, d_maxlen);
                 hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS,
-                                   count, isa);
+                                   count, isa, d_maxlen);
             }
             h *= 2;
         }
