@@ -75,7 +75,7 @@ void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
     void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
-                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos};
+                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->pairs1, ctx->pairs2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

@@ -1,0 +1,196 @@
+// isa.hip -- inverse suffix array (isa[SA[i]] = i) without random HBM writes.
+//
+// A direct scatter issues n random 4-byte writes (measured 140 ms for n = 3.1 G: every write is a partial line).
+// SA is a permutation, so every window of W consecutive positions receives exactly W entries -- the bin sizes of
+// a partition by position are known in advance, no histogram pass is needed and the order inside a bin is
+// irrelevant.  Two levels:
+//   level 1: (position, index) pairs partitioned on position >> 24 into bins of exactly 2^24 pairs
+//            (one streaming pass over SA; a workgroup reserves room per bin with one global atomic);
+//   level 2: per level-1 bin (128 MiB of pairs, processed while it is still in the last-level cache):
+//            partition on the next 8 bits into a small scratch, then scatter into the bin's 64 MiB window of isa
+//            through 256 KiB sub-windows that live in L2, so isa lines leave the cache complete.
+// Used by the PREFIX_DOUBLING refinement (lms_sort.hip: kiss_exact_refine).
+#include "kiss_internal.hpp"
+#include <cstdlib>
+
+namespace {
+
+constexpr int IB_THREADS = 1024;
+constexpr int IB_ITEMS = 16;
+constexpr int IB_TILE = IB_THREADS * IB_ITEMS; // 16384 pairs = 128 KiB of LDS staging
+constexpr int L1_SHIFT = 24;                   // level-1 bin = 2^24 positions
+constexpr int L2_SHIFT = 16;                   // level-2 bin = 2^16 positions (256 KiB of isa)
+constexpr int CUR_STRIDE = 64;                 // one bin cursor per 256 B: the reservations spread over channels
+
+// Partition one tile by an 8-bit digit.  FROM_SA: items are SA[base + i] (pair = position << 32 | index), else
+// items are pairs.  digit = (position >> shift) & 255.  Bin d of the output starts at out + ((uint64_t)d <<
+// bin_shift) and `cursor[d]` counts the pairs already placed there.
+template <bool FROM_SA>
+__global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__restrict__ SA,
+                                                             const uint64_t *__restrict__ pairs_in, uint64_t base,
+                                                             uint64_t count, int shift, int bin_shift,
+                                                             uint32_t *__restrict__ cursor, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t stage[IB_TILE];
+    __shared__ uint32_t lcnt[256];  // items of this tile per bin
+    __shared__ uint32_t loff[256];  // exclusive prefix of lcnt
+    __shared__ uint32_t gpos[256];  // where this tile's items of bin d start inside bin d
+    __shared__ uint32_t wsum[IB_THREADS / 64];
+    const uint64_t tile_base = (uint64_t)blockIdx.x * IB_TILE;
+    const uint32_t tile_count = (uint32_t)(count - tile_base < (uint64_t)IB_TILE ? count - tile_base : IB_TILE);
+    if (threadIdx.x < 256) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t pr[IB_ITEMS];
+    uint32_t rk[IB_ITEMS];
+#pragma unroll
+    for (int j = 0; j < IB_ITEMS; j++) {
+        const uint32_t li = threadIdx.x + (uint32_t)j * IB_THREADS;
+        if (li < tile_count) {
+            const uint64_t g = tile_base + li;
+            pr[j] = FROM_SA ? (((uint64_t)SA[base + g] << 32) | (base + g)) : pairs_in[g];
+        } else
+            pr[j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < IB_ITEMS; j++) {
+        const uint32_t li = threadIdx.x + (uint32_t)j * IB_THREADS;
+        if (li < tile_count) {
+            const uint32_t d = (uint32_t)(pr[j] >> (32 + shift)) & 255u;
+            // rank inside (tile, bin), < 16384.  A wave whose 64 items share one bin (sorted stretches of SA, e.g.
+            // runs of one base) takes one LDS atomic instead of 64 colliding ones.
+            const uint32_t d0 = __shfl(d, 0, 64);
+            if (__all(d == d0) && __popcll(__ballot(1)) == 64) {
+                uint32_t b0 = 0;
+                if (lane_id() == 0) b0 = atomicAdd(&lcnt[d], 64u);
+                rk[j] = (d << 16) | (__shfl(b0, 0, 64) + lane_id());
+            } else
+                rk[j] = (d << 16) | atomicAdd(&lcnt[d], 1u);
+        } else
+            rk[j] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    {
+        // exclusive scan of lcnt over the 256 digits (threads 0..255 = 4 waves) + one global reservation per bin
+        const bool dig = threadIdx.x < 256;
+        const uint32_t c = dig ? lcnt[threadIdx.x] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = __shfl_up(inc, dd, 64);
+            if ((int)lane_id() >= dd) inc += o;
+        }
+        if (dig && lane_id() == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        if (dig) {
+            uint32_t start = inc - c;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) start += wsum[w];
+            loff[threadIdx.x] = start;
+            gpos[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x * CUR_STRIDE], c) : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IB_ITEMS; j++)
+        if (rk[j] != 0xFFFFFFFFu) stage[loff[rk[j] >> 16] + (rk[j] & 0xFFFFu)] = pr[j];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < IB_ITEMS; r++) {
+        const uint32_t idx = threadIdx.x + (uint32_t)r * IB_THREADS;
+        if (idx < tile_count) {
+            const uint64_t v = stage[idx];
+            const uint32_t d = (uint32_t)(v >> (32 + shift)) & 255u;
+            out[((uint64_t)d << bin_shift) + gpos[d] + (idx - loff[d])] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_isa_write(const uint64_t *__restrict__ pairs, uint64_t count,
+                                                   uint32_t *__restrict__ isa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) {
+        const uint64_t v = pairs[i];
+        isa[v >> 32] = (uint32_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_isa_direct(const uint32_t *__restrict__ SA, uint64_t count,
+                                                    uint32_t *__restrict__ isa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) isa[SA[i]] = (uint32_t)i;
+}
+
+} // namespace
+
+// SA: a permutation of [0, total).  Scratch (ctx-owned, allocated on first use): pairs1 = round_up(total, 2^24)
+// u64, pairs2 = 2^24 u64 + the bin cursors.
+int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa)
+{
+    if (total == 0) return KISS_HIP_OK;
+    uint64_t direct_max = 1ull << 25; // 128 MiB of isa: the plain scatter stays in the last-level cache
+    if (const char *e = getenv("KISS_HIP_ISA_DIRECT_MAX")) direct_max = strtoull(e, nullptr, 10); // test hook
+    if (total <= direct_max) {
+        KTimer t(ctx, KISS_HIP_K_ISA, total);
+        hipLaunchKernelGGL(k_isa_direct, dim3((unsigned)div_up(total, 256)), dim3(256), 0, ctx->stream, SA, total, isa);
+        KCHECK(hipGetLastError());
+        return KISS_HIP_OK;
+    }
+    const uint64_t bins = div_up(total, 1ull << L1_SHIFT);
+    if (bins > 256) return KINTERNAL(); // total < 2^32
+    const uint64_t need1 = bins << L1_SHIFT;
+    if (ctx->pairs_cap < need1) {
+        if (ctx->pairs1) (void)hipFree(ctx->pairs1);
+        ctx->pairs1 = nullptr;
+        ctx->ws_bytes -= ctx->pairs_cap * sizeof(uint64_t);
+        ctx->pairs_cap = 0;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, need1 * sizeof(uint64_t));
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            return KISS_HIP_E_NOMEM;
+        }
+        ctx->pairs1 = (uint64_t *)p;
+        ctx->pairs_cap = need1;
+        ctx->ws_bytes += need1 * sizeof(uint64_t);
+    }
+    if (!ctx->pairs2) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (sizeof(uint64_t) << L1_SHIFT) + 512 * CUR_STRIDE * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            return KISS_HIP_E_NOMEM;
+        }
+        ctx->pairs2 = (uint64_t *)p;
+        ctx->ws_bytes += (sizeof(uint64_t) << L1_SHIFT) + 512 * CUR_STRIDE * sizeof(uint32_t);
+    }
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(ctx->pairs2 + (1ull << L1_SHIFT)); // 256 strided cursors for level 1, 256 for level 2
+    KTRY(kiss_zero_u32(ctx, cursor, 256 * CUR_STRIDE));
+    {
+        KTimer t(ctx, KISS_HIP_K_ISA, total);
+        hipLaunchKernelGGL((k_isa_partition<true>), dim3((unsigned)div_up(total, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
+                           SA, nullptr, 0ull, total, L1_SHIFT, L1_SHIFT, cursor, ctx->pairs1);
+        KCHECK(hipGetLastError());
+    }
+    KTimer t(ctx, KISS_HIP_K_ISA, total);
+    for (uint64_t b = 0; b < bins; b++) {
+        const uint64_t lo = b << L1_SHIFT;
+        const uint64_t cnt = total - lo < (1ull << L1_SHIFT) ? total - lo : (1ull << L1_SHIFT);
+        KTRY(kiss_zero_u32(ctx, cursor + 256 * CUR_STRIDE, 256 * CUR_STRIDE));
+        hipLaunchKernelGGL((k_isa_partition<false>), dim3((unsigned)div_up(cnt, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
+                           nullptr, ctx->pairs1 + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + 256 * CUR_STRIDE, ctx->pairs2);
+        // pairs2 is bin-major with 2^16-pair bins; in a short last bin the sub-bins are not full: write bin by bin
+        if (cnt == (1ull << L1_SHIFT)) {
+            hipLaunchKernelGGL(k_isa_write, dim3((unsigned)div_up(cnt, 256)), dim3(256), 0, ctx->stream, ctx->pairs2, cnt,
+                               isa);
+        } else {
+            for (uint64_t s = 0; s < 256 && (s << L2_SHIFT) < cnt; s++) {
+                const uint64_t c2 = cnt - (s << L2_SHIFT) < (1ull << L2_SHIFT) ? cnt - (s << L2_SHIFT) : (1ull << L2_SHIFT);
+                hipLaunchKernelGGL(k_isa_write, dim3((unsigned)div_up(c2, 256)), dim3(256), 0, ctx->stream,
+                                   ctx->pairs2 + (s << L2_SHIFT), c2, isa);
+            }
+        }
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}

@@ -73,6 +73,9 @@ struct kiss_hip_ctx {
     uint64_t ind_tiles_cap = 0;
     uint32_t *d_small = nullptr;   // small scratch (64 u32) for single-workgroup kernels
     uint32_t *h_pinned = nullptr;  // 64 u32 pinned host scratch
+    // PREFIX_DOUBLING: (position, index) pairs of the binned inverse-suffix-array build (isa.hip), allocated on first use
+    uint64_t *pairs1 = nullptr, *pairs2 = nullptr;
+    uint64_t pairs_cap = 0;
     // near-end
     uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr;
     uint64_t near_cap = 0;
@@ -122,6 +125,8 @@ int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_
 int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // exact order from an h0-ordered SA by rank doubling over the full suffix array (lms_sort.hip)
 int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA);
+// isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)
+int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // induced sort sweeps -> d_SA

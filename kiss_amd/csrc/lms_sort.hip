@@ -618,26 +618,6 @@ __global__ __launch_bounds__(LS_THREADS) void k_isa_init(const uint32_t *__restr
     if (i < count) isa[SA[i]] = (uint32_t)i;
 }
 
-// inverse of a permutation without random HBM writes: (position, index) pairs are binned on the top 8 bits of
-// the position (one stable radix pass), so the final scatter walks the inverse array window by window
-// (2^24 entries = 64 MiB, which the 256 MiB last-level cache absorbs)
-__global__ __launch_bounds__(LS_THREADS) void k_isa_pairs(const uint32_t *__restrict__ SA, uint64_t base, uint64_t count,
-                                                         uint64_t *__restrict__ key)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i < count) key[i] = ((uint64_t)SA[base + i] << 32) | (base + i);
-}
-
-__global__ __launch_bounds__(LS_THREADS) void k_isa_from_pairs(const uint64_t *__restrict__ key, uint64_t count,
-                                                              uint32_t *__restrict__ isa)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i < count) {
-        const uint64_t k = key[i];
-        isa[k >> 32] = (uint32_t)k;
-    }
-}
-
 // rank of a tied suffix = slot of the first member of its group
 // (also reports the longest group: *maxlen, zeroed by the caller; segstart[nseg] = count)
 __global__ __launch_bounds__(LS_THREADS) void k_isa_update(const uint32_t *__restrict__ pos,
@@ -753,44 +733,11 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
                                total, h0, heads);
         }
-        if (total <= (1ull << 26) || getenv("KISS_HIP_ISA_DIRECT")) { // the whole inverse array is cache resident
+        if (getenv("KISS_HIP_ISA_DIRECT")) { // measurement hook: the plain random scatter
             KTimer t(ctx, KISS_HIP_K_ISA, total);
             hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
-        } else {
-            uint64_t chunk = ctx->m_cap;
-            void *tmp[4] = {nullptr, nullptr, nullptr, nullptr};
-            if (getenv("KISS_HIP_ISA_ONECHUNK")) { // experiment
-                chunk = total;
-                KCHECK(hipMalloc(&tmp[0], total * 8));
-                KCHECK(hipMalloc(&tmp[1], total * 8));
-                KCHECK(hipMalloc(&tmp[2], total * 4));
-                KCHECK(hipMalloc(&tmp[3], total * 4));
-            }
-            for (uint64_t base = 0; base < total && rc == KISS_HIP_OK; base += chunk) {
-                const uint64_t cnt = total - base < chunk ? total - base : chunk;
-                RadixBufs rb;
-                rb.key[0] = tmp[0] ? (uint64_t *)tmp[0] : ctx->keyA;
-                rb.key[1] = tmp[0] ? (uint64_t *)tmp[1] : ctx->keyB;
-                rb.pos[0] = tmp[0] ? (uint32_t *)tmp[2] : ctx->posA; // payload not used here
-                rb.pos[1] = tmp[0] ? (uint32_t *)tmp[3] : ctx->posB;
-                rb.seg[0] = rb.seg[1] = nullptr;
-                {
-                    KTimer t(ctx, KISS_HIP_K_ISA, cnt);
-                    hipLaunchKernelGGL(k_isa_pairs, dim3((unsigned)div_up(cnt, T)), dim3(T), 0, ctx->stream, d_SA, base, cnt,
-                                       rb.key[0]);
-                }
-                int res = 0;
-                if ((rc = kiss_radix_sort(ctx, rb, cnt, 56, 0, &res))) break;
-                KTimer t(ctx, KISS_HIP_K_ISA, cnt);
-                hipLaunchKernelGGL(k_isa_from_pairs, dim3((unsigned)div_up(cnt, T)), dim3(T), 0, ctx->stream, rb.key[res],
-                                   cnt, isa);
-            }
-            if (tmp[0]) {
-                (void)hipStreamSynchronize(ctx->stream);
-                for (auto &t : tmp) (void)hipFree(t);
-            }
-            if (rc) break;
-        }
+        } else if ((rc = kiss_isa_build(ctx, d_SA, total, isa)))
+            break;
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
         if ((rc = fc_read_total(ctx, d_total, &tot))) break;

@@ -172,3 +172,21 @@ def test_prefix_doubling_small_and_depths(ctx, oracle, monkeypatch):
         monkeypatch.setenv("KISS_HIP_DOUBLING_H0", h0)
         st = _exact_by_doubling(ctx, oracle, S)
         assert st["refine_depth"] == int(h0)
+
+
+def test_prefix_doubling_binned_inverse(oracle, monkeypatch):
+    # the inverse suffix array of the doubling phase is built by a two-level partition (isa.hip) once it no longer
+    # fits the last-level cache; force that path at a size the oracle still sorts in seconds:
+    # two level-1 bins, the second one short (a few full level-2 bins + a partial one)
+    import kiss_amd
+    monkeypatch.setenv("KISS_HIP_ISA_DIRECT_MAX", "1000")
+    n = (1 << 24) + 5 * (1 << 16) + 12345
+    S = gen.genome_like(n, 21)
+    S[1000:9000] = 2                      # sorted stretches of SA (one-bin waves in the partition)
+    S[2_000_000:2_300_000] = S[9_000_000:9_300_000]
+    c = kiss_amd.Context(max_n=n, device=0)
+    try:
+        st = _exact_by_doubling(c, oracle, S)
+        assert st["refine_items"] > 300_000
+    finally:
+        c.close()
