@@ -134,13 +134,27 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
     hipEvent_t ev[7];
     for (auto &e : ev) KCHECK(hipEventCreate(&e));
     int rc = KISS_HIP_OK;
-    do {
+    for (int attempt = 0; attempt < 2; attempt++) {
         (void)hipEventRecord(ev[0], ctx->stream);
         if ((rc = kiss_pack_text(ctx, d_S, n))) break;
         (void)hipEventRecord(ev[1], ctx->stream);
         if ((rc = kiss_classify(ctx, n, depth, 0, n))) break;
         (void)hipEventRecord(ev[2], ctx->stream);
-        if ((rc = kiss_lms_sort(ctx, n, k, depth))) break;
+        rc = kiss_lms_sort(ctx, n, k, depth);
+        if (rc == KISS_INTERNAL_TOO_DEEP && attempt == 0 && n >= 4ull * 256 + 1024) {
+            // exact order requested through PARALLEL_SORTING on a text with very long repeats: same result via
+            // the bounded phase + rank doubling (the k-ordered stage outputs then belong to k = 256)
+            (void)hipStreamSynchronize(ctx->stream);
+            h0 = 256;
+            k = h0;
+            depth = (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
+            ctx->stats.refine_depth = h0;
+            ctx->stats.lms_rounds = 0;
+            ctx->stats.sort_item_rounds = ctx->stats.big_item_rounds = 0;
+            continue;
+        }
+        if (rc == KISS_INTERNAL_TOO_DEEP) rc = KINTERNAL();
+        if (rc) break;
         (void)hipEventRecord(ev[3], ctx->stream);
         if ((rc = kiss_place_lms(ctx, n, k, depth))) break;
         (void)hipEventRecord(ev[4], ctx->stream);
@@ -163,7 +177,8 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         ctx->stats.ms_place = ms[3];
         ctx->stats.ms_induce = ms[4];
         (void)hipEventElapsedTime(&ctx->stats.ms_total, ev[0], ev[6]);
-    } while (0);
+        break;
+    }
     if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
     ctx->stats.m = ctx->m;
     ktimer_collect(ctx);

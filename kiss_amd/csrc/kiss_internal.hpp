@@ -123,6 +123,9 @@ struct RadixBufs {
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
 // k-ordered LMS sort of the far suffixes -> ctx->lms_sorted_far
 int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
+// kiss_lms_sort in exact mode gives up (no output) once suffixes still tie after this many bases
+constexpr uint64_t KISS_EXACT_MSD_MAX_DEPTH = 32768;
+constexpr int KISS_INTERNAL_TOO_DEEP = 1000; // never crosses the ABI
 // exact order from an h0-ordered SA by rank doubling over the full suffix array (lms_sort.hip)
 int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA);
 // isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)

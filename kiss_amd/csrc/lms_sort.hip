@@ -555,6 +555,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         nseg = tot & 0xFFFFFFFFull;
         off += 32;
         if (!depth && off > n + 64 && count > 0) return KINTERNAL(); // exact mode must have terminated
+        // exact order, repeats longer than this: 32 bases per round is the wrong tool, the caller switches to
+        // rank doubling (same result)
+        if (!depth && off >= KISS_EXACT_MSD_MAX_DEPTH && count > 0) return KISS_INTERNAL_TOO_DEEP;
     }
     return KISS_HIP_OK;
 }

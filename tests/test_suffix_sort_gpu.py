@@ -190,3 +190,21 @@ def test_prefix_doubling_binned_inverse(oracle, monkeypatch):
         assert st["refine_items"] > 300_000
     finally:
         c.close()
+
+
+def test_exact_msd_falls_back_to_doubling(ctx, oracle):
+    # PARALLEL_SORTING with k >= n compares 32 bases per round; past 32768 tied bases the library restarts
+    # through the doubling path (api.hip sort_dev) -- same, unique result
+    import kiss_amd
+    n = 200_000
+    S = np.tile(np.array([0, 2, 1, 3, 3, 0, 1], np.uint8), n // 7 + 1)[:n]
+    sa = ctx.suffix_sort(S, kiss_amd.K_UNBOUNDED, algo=0)
+    st = ctx.stats()
+    assert st["refine_depth"] == 256 and st["doubling_rounds"] >= 1
+    assert np.array_equal(sa, oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED))
+    # a repeat shorter than the switch-over depth stays on the 32-bases-per-round path
+    S2 = gen.iid(n, 31)
+    S2[100_000:120_000] = S2[10_000:30_000]
+    sa2 = ctx.suffix_sort(S2, kiss_amd.K_UNBOUNDED, algo=0)
+    assert ctx.stats()["refine_depth"] == 0
+    assert np.array_equal(sa2, oracle.suffix_sort(S2, kiss_amd.K_UNBOUNDED))
