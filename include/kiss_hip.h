@@ -37,7 +37,8 @@ typedef enum kiss_hip_status {
     KISS_HIP_E_HIP = -3,         /* a HIP runtime call failed (see kiss_hip_last_hip_error) */
     KISS_HIP_E_NOMEM = -4,       /* device or host allocation failed */
     KISS_HIP_E_UNSUPPORTED = -5, /* valid request outside the implemented range (documented) */
-    KISS_HIP_E_INTERNAL = -6     /* an internal invariant failed (bug) */
+    KISS_HIP_E_INTERNAL = -6,    /* an internal invariant failed (bug) */
+    KISS_HIP_E_IO = -7           /* a file could not be opened / read */
 } kiss_hip_status;
 
 /* Sorting algorithm selector; mirrors kISS::SortingAlgorithm
@@ -238,6 +239,23 @@ int kiss_hip_fmi_query_batch_host(const kiss_hip_fmi_view *fmi, const uint8_t *p
                                   uint32_t *beg, uint32_t *end, uint64_t *hit_count_total, uint64_t *checksum,
                                   uint32_t *offsets, uint64_t *offsets_index, uint64_t offsets_capacity, int device);
 
+/* ---- FASTA / plain-text input parsed on the device (replaces read_sequence, include/utils/io.hpp:6-18, and the
+ * `c % 4` of command/suffix_sort.hpp:33; record rules of biovoltron/file_io/fasta.hpp:117-151) ------------------
+ * The file is FASTA iff its first byte is '>'.  Header lines are dropped, every other byte except '\n' is a base:
+ * A/a 0, C/c 1, G/g 2, T/t 3, anything else 0 (the reference maps it to 4 and reduces % 4; that includes '\r').
+ * kiss_hip_ctx_parse_text_dev: raw file bytes already in device memory -> codes in d_S (capacity >= bytes), *n_out
+ *   = number of bases.  The ctx must have been created with max_n >= bytes / 1000.
+ * kiss_hip_ctx_load_text_file: streams the file through pinned buffers into device memory and parses it there;
+ *   *d_S_out is a device buffer owned by the caller (kiss_hip_free_dev).  No base is touched on the host.
+ * kiss_hip_alloc_dev / kiss_hip_copy_to_host / kiss_hip_free_dev: for hosts that do not link HIP (the CLI, ctypes);
+ *   they act on the current device of the calling thread (the one the last ctx call selected). */
+int kiss_hip_file_size(const char *path, uint64_t *bytes);
+int kiss_hip_ctx_parse_text_dev(kiss_hip_ctx *ctx, const uint8_t *d_raw, uint64_t bytes, uint8_t *d_S, uint64_t *n_out,
+                                void *stream);
+int kiss_hip_ctx_load_text_file(kiss_hip_ctx *ctx, const char *path, uint8_t **d_S_out, uint64_t *n_out);
+int kiss_hip_alloc_dev(void **d_out, uint64_t bytes);
+int kiss_hip_copy_to_host(void *dst, const void *d_src, uint64_t bytes);
+int kiss_hip_free_dev(void *p);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,16 @@ def load():
     lib.kiss_hip_fmi_build_dev.argtypes = [
         vp, vp, ctypes.c_uint64, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp,
         ctypes.POINTER(ctypes.c_uint32 * 4), ctypes.POINTER(ctypes.c_uint32), vp]
+    lib.kiss_hip_file_size.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
+    lib.kiss_hip_ctx_parse_text_dev.argtypes = [vp, vp, u64, vp, ctypes.POINTER(u64), vp]
+    lib.kiss_hip_ctx_load_text_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    lib.kiss_hip_copy_to_host.argtypes = [vp, vp, u64]
+    lib.kiss_hip_free_dev.argtypes = [vp]
+    lib.kiss_hip_alloc_dev.argtypes = [ctypes.POINTER(vp), u64]
+    lib.kiss_hip_alloc_dev.restype = ctypes.c_int
+    for name in ("kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file",
+                 "kiss_hip_copy_to_host", "kiss_hip_free_dev"):
+        getattr(lib, name).restype = ctypes.c_int
     for name in ("kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy", "kiss_hip_ctx_set_profiling",
                  "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
                  "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32",
@@ -130,4 +140,6 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
     "kiss_hip_stage_sort", "kiss_hip_stage_induce",
     "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
+    "kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file", "kiss_hip_copy_to_host",
+    "kiss_hip_free_dev", "kiss_hip_alloc_dev",
 ]

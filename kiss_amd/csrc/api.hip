@@ -247,6 +247,7 @@ const char *kiss_hip_strerror(int status)
     case KISS_HIP_E_NOMEM: return "out of memory";
     case KISS_HIP_E_UNSUPPORTED: return "request outside the implemented range";
     case KISS_HIP_E_INTERNAL: return "internal invariant violated";
+    case KISS_HIP_E_IO: return "file could not be opened or read";
     default: return "unknown status";
     }
 }

@@ -62,26 +62,47 @@ inline uint8_t to_code(unsigned char c)
     }
 }
 
-// utils/io.hpp:6-18
-std::vector<uint8_t> read_sequence(const std::string &path)
-{
-    std::ifstream in(path, std::ios::binary);
-    if (!in) throw std::runtime_error("cannot open " + path);
-    std::vector<uint8_t> seq;
-    std::string line;
-    const bool fasta = in.peek() == '>';
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (fasta && !line.empty() && line[0] == '>') continue;
-        for (unsigned char c : line) seq.push_back(to_code(c));
-    }
-    return seq;
-}
-
 void check(int rc, const char *where)
 {
     if (rc != KISS_HIP_OK) throw std::runtime_error(std::string(where) + ": " + kiss_hip_strerror(rc));
 }
+
+// utils/io.hpp:6-18 (read_sequence) + the `% 4` of the commands: the file is streamed to the device and parsed there
+// (kiss_amd/csrc/fasta.hip); the host never touches a base
+struct DeviceText {
+    kiss_hip_ctx *ctx = nullptr;
+    uint8_t *d_S = nullptr;
+    uint64_t n = 0;
+    double create_s = 0, load_s = 0;
+    DeviceText(const std::string &path, int device)
+    {
+        uint64_t bytes = 0;
+        if (kiss_hip_file_size(path.c_str(), &bytes) != KISS_HIP_OK) throw std::runtime_error("cannot open " + path);
+        auto t0 = std::chrono::steady_clock::now();
+        check(kiss_hip_ctx_create(&ctx, device, bytes ? bytes : 1), "kiss_hip_ctx_create");
+        create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        t0 = std::chrono::steady_clock::now();
+        const int rc = kiss_hip_ctx_load_text_file(ctx, path.c_str(), &d_S, &n);
+        load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc != KISS_HIP_OK) {
+            kiss_hip_ctx_destroy(ctx);
+            throw std::runtime_error(std::string("kiss_hip_ctx_load_text_file: ") + kiss_hip_strerror(rc));
+        }
+    }
+    std::vector<uint8_t> to_host() const
+    {
+        std::vector<uint8_t> S(n);
+        check(kiss_hip_copy_to_host(S.data(), d_S, n), "kiss_hip_copy_to_host");
+        return S;
+    }
+    ~DeviceText()
+    {
+        kiss_hip_free_dev(d_S);
+        kiss_hip_ctx_destroy(ctx);
+    }
+    DeviceText(const DeviceText &) = delete;
+    DeviceText &operator=(const DeviceText &) = delete;
+};
 
 struct Args {
     std::string command, fasta, query, batch, output_sa, algo = "PARALLEL_SORTING";
@@ -217,43 +238,53 @@ struct Fmi {
 
 int suffix_sort_main(const Args &a)
 {
-    auto S = read_sequence(a.fasta);
+    DeviceText T(a.fasta, a.device);
     int algo;
     if (a.algo == "PARALLEL_SORTING") algo = KISS_HIP_ALGO_PARALLEL_SORTING;
     else if (a.algo == "PREFIX_DOUBLING") algo = KISS_HIP_ALGO_PREFIX_DOUBLING;
     else throw std::invalid_argument("Invalid sorting algorithm");
     const uint32_t k = (uint32_t)(uint64_t)a.k; // -1 -> size_t max -> truncated to 0xFFFFFFFF (suffix_sort.hpp:35-37)
-    std::vector<uint32_t> SA(S.size() + 1);
+    void *d_SA = nullptr;
+    check(kiss_hip_alloc_dev(&d_SA, (T.n + 1) * sizeof(uint32_t)), "kiss_hip_alloc_dev");
     const auto t0 = std::chrono::steady_clock::now(); // the reference starts its stopwatch here (suffix_sort.hpp:57)
-    kiss_hip_ctx *ctx = nullptr;
-    if (S.empty()) SA[0] = 0;
-    else {
-        check(kiss_hip_ctx_create(&ctx, a.device, S.size()), "kiss_hip_ctx_create");
-        check(kiss_hip_ctx_suffix_sort_dna_u32(ctx, S.data(), S.size(), k, algo, SA.data()), "kiss_hip_ctx_suffix_sort_dna_u32");
-    }
+    check(kiss_hip_ctx_suffix_sort_dna_u32_dev(T.ctx, T.d_S, T.n, k, algo, (uint32_t *)d_SA, nullptr),
+          "kiss_hip_ctx_suffix_sort_dna_u32_dev");
     const double el = seconds_since(t0);
-    std::fprintf(stderr, "[info] n = %zu, k = %llu, suffix sorting elapsed %.6f\n", S.size(),
+    std::fprintf(stderr, "[info] n = %llu, k = %llu, suffix sorting elapsed %.6f\n", (unsigned long long)T.n,
                  (unsigned long long)(a.k < 0 ? ~0ull : (unsigned long long)a.k), el);
-    if (a.verbose && ctx) {
+    if (a.verbose) {
         kiss_hip_stats st;
-        kiss_hip_get_stats(ctx, &st);
+        kiss_hip_get_stats(T.ctx, &st);
+        std::fprintf(stderr, "[debug] device workspace %.6f s; read + upload + device-side parse of %s %.6f s\n", T.create_s,
+                     a.fasta.c_str(), T.load_s);
         std::fprintf(stderr,
                      "[debug] device: pack %.3f ms, get_lms %.3f ms, lms_suffix_direct_sort %.3f ms, put_lms_suffix %.3f ms, "
-                     "induced_sort %.3f ms, total %.3f ms; lms = %llu, rounds = %u, passes = %u\n",
-                     st.ms_pack, st.ms_classify, st.ms_lms_sort, st.ms_place, st.ms_induce, st.ms_total,
-                     (unsigned long long)st.m, st.lms_rounds, st.induce_passes);
+                     "induced_sort %.3f ms, prefix_doubling %.3f ms, total %.3f ms; lms = %llu, rounds = %u + %u, passes = %u\n",
+                     st.ms_pack, st.ms_classify, st.ms_lms_sort, st.ms_place, st.ms_induce, st.ms_refine, st.ms_total,
+                     (unsigned long long)st.m, st.lms_rounds, st.doubling_rounds, st.induce_passes);
     }
-    if (ctx) kiss_hip_ctx_destroy(ctx);
     if (!a.output_sa.empty()) {
         std::ofstream o(a.output_sa, std::ios::binary);
-        o.write(reinterpret_cast<const char *>(SA.data()), (std::streamsize)(SA.size() * 4));
+        if (!o) throw std::runtime_error("cannot write " + a.output_sa);
+        const uint64_t total = T.n + 1, chunk = 64ull << 20; // entries per piece
+        std::vector<uint32_t> buf((size_t)std::min<uint64_t>(total, chunk));
+        for (uint64_t off = 0; off < total; off += chunk) {
+            const uint64_t c = std::min<uint64_t>(chunk, total - off);
+            check(kiss_hip_copy_to_host(buf.data(), (const uint32_t *)d_SA + off, c * sizeof(uint32_t)), "kiss_hip_copy_to_host");
+            o.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize)(c * sizeof(uint32_t)));
+        }
     }
+    kiss_hip_free_dev(d_SA);
     return 0;
 }
 
 int fmindex_build_main(const Args &a)
 {
-    auto S = read_sequence(a.fasta);
+    std::vector<uint8_t> S;
+    {
+        DeviceText T(a.fasta, a.device);
+        S = T.to_host();
+    }
     if (S.empty()) throw std::runtime_error("empty sequence");
     Fmi f;
     f.alloc(S.size());
@@ -276,7 +307,11 @@ const char *ending(size_t x)
 
 int fmindex_query_main(const Args &a)
 {
-    auto S = read_sequence(a.fasta);
+    std::vector<uint8_t> S;
+    {
+        DeviceText T(a.fasta, a.device);
+        S = T.to_host();
+    }
     Fmi f;
     f.load(a.fasta + ".fmi");
     const kiss_hip_fmi_view v = f.view();

@@ -57,6 +57,30 @@ class Context:
         except Exception:
             pass
 
+    def load_text_file(self, path):
+        """FASTA / plain-text file -> (device pointer to base codes, n); parsed on the GPU (reference read_sequence,
+        include/utils/io.hpp:6-18).  Free the buffer with `free_dev`."""
+        d_S = ctypes.c_void_p()
+        n = ctypes.c_uint64()
+        _check(self._lib.kiss_hip_ctx_load_text_file(self._ctx, str(path).encode(), ctypes.byref(d_S), ctypes.byref(n)),
+               "kiss_hip_ctx_load_text_file", self._ctx)
+        return d_S.value, n.value
+
+    def free_dev(self, ptr):
+        if ptr:
+            _check(self._lib.kiss_hip_free_dev(ctypes.c_void_p(ptr)), "kiss_hip_free_dev")
+
+    def read_sequence(self, path):
+        """the base codes of a FASTA / plain-text file as a host numpy array (tests, small files)"""
+        ptr, n = self.load_text_file(path)
+        try:
+            out = np.empty(n, dtype=np.uint8)
+            if n:
+                _check(self._lib.kiss_hip_copy_to_host(out.ctypes.data, ctypes.c_void_p(ptr), n), "kiss_hip_copy_to_host")
+        finally:
+            self.free_dev(ptr)
+        return out
+
     def set_profiling(self, on):
         _check(self._lib.kiss_hip_ctx_set_profiling(self._ctx, 1 if on else 0), "kiss_hip_ctx_set_profiling")
 

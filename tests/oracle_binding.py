@@ -68,6 +68,15 @@ class Oracle:
         SA = np.ascontiguousarray(SA, dtype=np.uint32)
         return OracleFmi(lib, lib.ko_fmi_build(S.ctypes.data, S.size, SA.ctypes.data))
 
+    def read_sequence(self, raw):
+        """base codes of a FASTA / plain-text file given as bytes (oracle/kiss_oracle_io.c)"""
+        raw = np.frombuffer(bytes(raw), dtype=np.uint8)
+        out = np.empty(max(1, raw.size), dtype=np.uint8)
+        self.lib.ko_read_sequence.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        self.lib.ko_read_sequence.restype = ctypes.c_uint64
+        n = self.lib.ko_read_sequence(raw.ctypes.data if raw.size else None, raw.size, out.ctypes.data)
+        return out[:n].copy()
+
     def fnv(self, a):
         a = np.ascontiguousarray(a, dtype=np.uint32)
         return int(self.lib.ko_fnv1a64_u32(a.ctypes.data, a.size))

@@ -128,3 +128,18 @@ def test_golden_fixtures(oracle):
         if "SA" in z:
             assert np.array_equal(SA, z["SA"]), f
         assert oracle.fnv(SA) == int(z["sa_fnv"]), f
+
+
+def test_reader_known_answers(oracle):
+    # hand-derived from the reference's control flow (utils/io.hpp:6-18, file_io/fasta.hpp:117-151):
+    # header dropped, non-ACGT -> 4 % 4 = 0, a '>' line right after a header is sequence, the next one a header
+    A, C, G, T = 0, 1, 2, 3
+    got = oracle.read_sequence(b">h1 x\nACGT\nNNac\n>h2\n>zzA\n>h3\nTT")
+    assert got.tolist() == [A, C, G, T, A, A, A, C, A, A, A, A, T, T]
+    # text mode: every byte but '\n' is a base, '\r' included; '>' lines are not special
+    assert oracle.read_sequence(b"ACGT\r\n>x\nGG").tolist() == [A, C, G, T, A, A, A, G, G]
+    assert oracle.read_sequence(b"").size == 0
+    assert oracle.read_sequence(b">only a header").size == 0
+    assert oracle.read_sequence(b">h\n\n\nAC\n\nGT\n").tolist() == [A, C, G, T]
+    assert oracle.read_sequence(b"\nAC").tolist() == [A, C]          # starts with '\n': text mode
+    assert oracle.read_sequence(b">h\r\nAC\r\n").tolist() == [A, C, A]  # CRLF: the '\r' of a sequence line is a base
