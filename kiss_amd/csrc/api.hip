@@ -4,6 +4,7 @@
 // (reference include/biovoltron/algo/sort/kiss1_core.hpp:229-268):
 //   pack -> get_lms -> k-ordered LMS sort -> (near-end rule, merge, context gather) -> L/S induction.
 #include "kiss_internal.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -54,13 +55,28 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
     return KISS_HIP_OK;
 }
 
+void free_tied(kiss_hip_ctx *ctx)
+{
+    void **ptrs[] = {(void **)&ctx->segA, (void **)&ctx->segB, (void **)&ctx->slotA, (void **)&ctx->slotB,
+                     (void **)&ctx->segstartA, (void **)&ctx->segstartB, (void **)&ctx->bkeyA, (void **)&ctx->bkeyB,
+                     (void **)&ctx->bposA, (void **)&ctx->bposB, (void **)&ctx->bsegA, (void **)&ctx->bsegB,
+                     (void **)&ctx->bslot, (void **)&ctx->flags};
+    for (void **p : ptrs)
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    ctx->ws_bytes -= ctx->tied_bytes;
+    ctx->tied_bytes = 0;
+    ctx->t_cap = 0;
+    ctx->flags_cap = 0;
+}
+
 void free_lms_side(kiss_hip_ctx *ctx)
 {
+    free_tied(ctx);
     void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
-                     (void **)&ctx->posB, (void **)&ctx->segA, (void **)&ctx->segB, (void **)&ctx->slotA,
-                     (void **)&ctx->slotB, (void **)&ctx->segstartA, (void **)&ctx->segstartB, (void **)&ctx->bkeyA,
-                     (void **)&ctx->bkeyB, (void **)&ctx->bposA, (void **)&ctx->bposB, (void **)&ctx->bsegA,
-                     (void **)&ctx->bsegB, (void **)&ctx->bslot, (void **)&ctx->flags, (void **)&ctx->lms_sorted_far,
+                     (void **)&ctx->posB, (void **)&ctx->lms_sorted_far,
                      (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp};
     for (void **p : ptrs)
         if (*p) {
@@ -208,20 +224,6 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         ALLOC(keyB, m_cap);
         ALLOC(posA, m_cap);
         ALLOC(posB, m_cap);
-        ALLOC(segA, m_cap);
-        ALLOC(segB, m_cap);
-        ALLOC(slotA, m_cap);
-        ALLOC(slotB, m_cap);
-        ALLOC(segstartA, m_cap + 2);
-        ALLOC(segstartB, m_cap + 2);
-        ALLOC(bkeyA, m_cap);
-        ALLOC(bkeyB, m_cap);
-        ALLOC(bposA, m_cap);
-        ALLOC(bposB, m_cap);
-        ALLOC(bsegA, m_cap);
-        ALLOC(bsegB, m_cap);
-        ALLOC(bslot, m_cap);
-        ALLOC(flags, 2 * m_cap);
         ALLOC(lms_sorted_far, m_cap);
         ALLOC(lmsP, m_cap);
         ALLOC(lmsC, m_cap);
@@ -230,6 +232,53 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
 #undef ALLOC
     } while (0);
     ctx->lms_bytes = ctx->ws_bytes - before;
+    if (rc) return rc;
+    // tied-segment arrays: on genome-like text 18 % of the LMS suffixes survive round 0; they grow on demand
+    // (all-tied inputs such as periodic texts end up at m_cap)
+    uint64_t t0 = m_cap / 4 + (4ull << 20);
+    if (t0 > m_cap) t0 = m_cap;
+    if (const char *e = getenv("KISS_HIP_TCAP0")) { // test hook: start small so that every growth path runs
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 1 && v < t0) t0 = v;
+    }
+    return kiss_tied_reserve(ctx, t0);
+}
+
+int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
+{
+    free_tied(ctx);
+    if (t_cap < 1024) t_cap = 1024;
+    const uint64_t before = ctx->ws_bytes;
+    // `flags` also holds the per-tile words of the fused flag + compaction over all m (or, for the doubling phase,
+    // n + 1) items: 2 words per 2048-item tile
+    uint64_t fcap = 2 * t_cap;
+    const uint64_t tiles_m = 2 * (ctx->m_cap / 2048 + 2), tiles_n = 2 * ((ctx->max_n + 1) / 2048 + 2);
+    if (fcap < tiles_m) fcap = tiles_m;
+    if (fcap < tiles_n) fcap = tiles_n;
+    int rc = KISS_HIP_OK;
+    do {
+#define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
+        ALLOC(segA, t_cap);
+        ALLOC(segB, t_cap);
+        ALLOC(slotA, t_cap);
+        ALLOC(slotB, t_cap);
+        ALLOC(segstartA, t_cap + 2);
+        ALLOC(segstartB, t_cap + 2);
+        ALLOC(bkeyA, t_cap);
+        ALLOC(bkeyB, t_cap);
+        ALLOC(bposA, t_cap);
+        ALLOC(bposB, t_cap);
+        ALLOC(bsegA, t_cap);
+        ALLOC(bsegB, t_cap);
+        ALLOC(bslot, t_cap);
+        ALLOC(flags, fcap);
+#undef ALLOC
+    } while (0);
+    ctx->tied_bytes = ctx->ws_bytes - before;
+    if (rc == KISS_HIP_OK) {
+        ctx->t_cap = t_cap;
+        ctx->flags_cap = fcap;
+    }
     return rc;
 }
 

@@ -266,6 +266,8 @@ int kiss_hip_ctx_parse_text_dev(kiss_hip_ctx *ctx, const uint8_t *d_raw, uint64_
     if (bytes == 0) return KISS_HIP_OK;
     const uint64_t tiles = div_up(bytes, FA_TILE);
     if (tiles + 2 > ctx->m_cap) return KISS_HIP_E_INVALID; // ctx too small for this file (max_n >= bytes is enough)
+    if (tiles + 2 > ctx->t_cap) KTRY(kiss_tied_reserve(ctx, tiles + 2));
+restart:
     uint32_t *tile_nl = ctx->segA, *nl_ex = ctx->segB, *tile_gt = ctx->slotA, *gt_ex = ctx->slotB;
     uint32_t *tile_keep = ctx->bsegA, *keep_ex = ctx->bsegB;
     uint32_t *gt_line = ctx->posA, *flag = ctx->posB, *run_ex = ctx->bposA, *run_start = ctx->bposB, *is_header = ctx->bslot;
@@ -284,6 +286,10 @@ int kiss_hip_ctx_parse_text_dev(kiss_hip_ctx *ctx, const uint8_t *d_raw, uint64_
         hipLaunchKernelGGL(k_fa_last, dim3(1), dim3(64), 0, ctx->stream, tile_gt, gt_ex, tiles, d_tot);
         KTRY(read_u32(ctx, d_tot, &G));
         if ((uint64_t)G + 2 > ctx->m_cap) return KISS_HIP_E_UNSUPPORTED; // a third of the lines are 1-2 bytes long
+        if ((uint64_t)G + 2 > ctx->t_cap) { // per-header scratch lives in the tied-segment arrays: regrow, start over
+            KTRY(kiss_tied_reserve(ctx, (uint64_t)G + 2));
+            goto restart;
+        }
         hipLaunchKernelGGL(k_fa_gt_lines, dim3((unsigned)tiles), dim3(FA_THREADS), 0, ctx->stream, d_raw, bytes, nl_ex, gt_ex,
                            gt_line);
         const unsigned gb = (unsigned)div_up(G, 256);

@@ -245,7 +245,9 @@ int suffix_sort_main(const Args &a)
     else throw std::invalid_argument("Invalid sorting algorithm");
     const uint32_t k = (uint32_t)(uint64_t)a.k; // -1 -> size_t max -> truncated to 0xFFFFFFFF (suffix_sort.hpp:35-37)
     void *d_SA = nullptr;
+    const auto ta = std::chrono::steady_clock::now();
     check(kiss_hip_alloc_dev(&d_SA, (T.n + 1) * sizeof(uint32_t)), "kiss_hip_alloc_dev");
+    const double alloc_s = seconds_since(ta);
     const auto t0 = std::chrono::steady_clock::now(); // the reference starts its stopwatch here (suffix_sort.hpp:57)
     check(kiss_hip_ctx_suffix_sort_dna_u32_dev(T.ctx, T.d_S, T.n, k, algo, (uint32_t *)d_SA, nullptr),
           "kiss_hip_ctx_suffix_sort_dna_u32_dev");
@@ -255,8 +257,8 @@ int suffix_sort_main(const Args &a)
     if (a.verbose) {
         kiss_hip_stats st;
         kiss_hip_get_stats(T.ctx, &st);
-        std::fprintf(stderr, "[debug] device workspace %.6f s; read + upload + device-side parse of %s %.6f s\n", T.create_s,
-                     a.fasta.c_str(), T.load_s);
+        std::fprintf(stderr, "[debug] device workspace %.6f s; read + upload + device-side parse of %s %.6f s; SA buffer %.6f s\n",
+                     T.create_s, a.fasta.c_str(), T.load_s, alloc_s);
         std::fprintf(stderr,
                      "[debug] device: pack %.3f ms, get_lms %.3f ms, lms_suffix_direct_sort %.3f ms, put_lms_suffix %.3f ms, "
                      "induced_sort %.3f ms, prefix_doubling %.3f ms, total %.3f ms; lms = %llu, rounds = %u + %u, passes = %u\n",
@@ -274,7 +276,9 @@ int suffix_sort_main(const Args &a)
             o.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize)(c * sizeof(uint32_t)));
         }
     }
+    const auto tf = std::chrono::steady_clock::now();
     kiss_hip_free_dev(d_SA);
+    if (a.verbose) std::fprintf(stderr, "[debug] SA buffer released in %.6f s\n", seconds_since(tf));
     return 0;
 }
 

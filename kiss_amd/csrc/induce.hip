@@ -631,7 +631,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
     uint64_t tot[4];
     bool done;
     if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "induce start"));
-    const uint64_t collapse_max = COLLAPSE_N < ctx->m_cap ? COLLAPSE_N : ctx->m_cap;
+    uint64_t collapse_max = COLLAPSE_N < ctx->m_cap ? COLLAPSE_N : ctx->m_cap; // chain scratch: m_cap- and t_cap-sized arrays
+    if (collapse_max > ctx->t_cap) collapse_max = ctx->t_cap;
 
     // ---------------- L sweep: left to right ----------------
     Sweep L{ctx, d_SA, +1, {(int64_t)start[0], (int64_t)start[1], (int64_t)start[2], (int64_t)start[3]}};

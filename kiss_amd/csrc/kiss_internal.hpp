@@ -37,7 +37,10 @@ struct kiss_hip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream of the current call
     uint64_t max_n = 0;
-    uint64_t m_cap = 0;            // capacity of LMS arrays
+    uint64_t m_cap = 0;            // capacity of the per-LMS arrays (every LMS suffix of the text)
+    uint64_t t_cap = 0;            // capacity of the tied-segment arrays (suffixes still tied after round 0)
+    uint64_t flags_cap = 0;        // u64 entries in `flags`
+    uint64_t tied_bytes = 0;
     uint64_t ws_bytes = 0;
     uint64_t lms_bytes = 0;
 
@@ -104,6 +107,9 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 // ---- stages (host drivers) -------------------------------------------------------
 // (re)allocates every LMS-sized array for at least m_cap suffixes
 int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
+// (re)allocates the tied-segment arrays (seg*, slot*, segstart*, bkey*, bpos*, bseg*, bslot, flags) for t_cap items;
+// their contents are lost
+int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap);
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
 // classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
 // only LMS suffixes / histogram contributions of text positions in [win_lo, win_hi) are produced (sharded runs)

@@ -342,8 +342,8 @@ int fc_count(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, uint64
              uint64_t *d_total)
 {
     const uint64_t tiles = div_up(count, FC_TILE);
-    if (2 * tiles > 2 * ctx->m_cap) return KINTERNAL();
-    uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles; // 2 * tiles u64 <= 2 * m_cap
+    if (2 * tiles > ctx->flags_cap) return KINTERNAL();
+    uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles;
     {
         KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
         hipLaunchKernelGGL((k_fc_count<SRC>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
@@ -439,8 +439,6 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                               ctx->stream));
         return KISS_HIP_OK;
     }
-    uint64_t *F1 = ctx->flags;
-    uint64_t *F2 = ctx->flags + ctx->m_cap;
     uint32_t *d_nbig = ctx->d_small + 8;
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     const unsigned T = LS_THREADS;
@@ -467,10 +465,19 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     ctx->stats.lms_rounds++;
     ctx->stats.sort_item_rounds += count;
     uint32_t *Pc = rb.pos[res ^ 1]; // receives the survivors' positions
-    uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
     uint64_t tot;
-    KTRY((fused_compact<false, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
-                                     d_total, &tot)));
+    KTRY((fc_count<FC_KEY>(ctx, rb.key[res], nullptr, count, r0_shift, 0, d_total)));
+    KTRY(fc_read_total(ctx, d_total, &tot));
+    if ((tot >> 32) > ctx->t_cap) { // more tied suffixes than the tied-segment arrays hold: regrow them (empty so far)
+        const uint64_t surv = tot >> 32;
+        KTRY(kiss_tied_reserve(ctx, surv + surv / 8 + 1024));
+        KTRY((fc_count<FC_KEY>(ctx, rb.key[res], nullptr, count, r0_shift, 0, d_total)));
+    }
+    uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
+    uint64_t *F1 = ctx->flags;
+    uint64_t *F2 = ctx->flags + ctx->t_cap;
+    KTRY((fc_compact<FC_KEY, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
+                                   ctx->lms_sorted_far, nullptr)));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     if (dbg)
@@ -750,11 +757,10 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffixes tied at depth %u in %llu groups\n",
                     (unsigned long long)count, (unsigned long long)total, h0, (unsigned long long)nseg);
         if (count == 0) break;
-        if (count > ctx->m_cap) { // regrow the LMS-side work buffers (their contents are dead); keeps CTX and pk
-            const uint64_t tiles = div_up(total, FC_TILE);
-            uint64_t want = count + count / 64 + 1024;
-            if (want < tiles) want = tiles;
-            if ((rc = kiss_lms_reserve(ctx, want))) break;
+        if (count > ctx->m_cap || count > ctx->t_cap) { // regrow the work buffers (their contents are dead); keeps CTX, pk
+            const uint64_t want = count + count / 64 + 1024;
+            if (count > ctx->m_cap && (rc = kiss_lms_reserve(ctx, want))) break;
+            if (count > ctx->t_cap && (rc = kiss_tied_reserve(ctx, want))) break;
             if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
         }
         uint32_t *P = ctx->posA, *P2 = ctx->posB;
@@ -787,7 +793,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             const uint32_t maxlen = (uint32_t)ml;
             // groups of <= 64 sort themselves in place; members of longer groups are pulled out, radix sorted on
             // (group, rank) and put back -- sorted keys in bkeyB, positions in bposB, group ids unchanged in G
-            uint64_t *F1 = ctx->flags, *F2 = ctx->flags + ctx->m_cap;
+            uint64_t *F1 = ctx->flags, *F2 = ctx->flags + ctx->t_cap;
             {
                 KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
                 hipLaunchKernelGGL(k_group_sort_small, dim3(grid), dim3(T), 0, ctx->stream, ctx->bkeyA, P, G, SS, count,

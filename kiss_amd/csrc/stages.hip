@@ -109,6 +109,7 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     if (count == 0) return KISS_HIP_OK;
+    if (count > ctx->t_cap) KTRY(kiss_tied_reserve(ctx, count + count / 64 + 1024)); // group ids use the segment arrays
     Splitters sp;
     sp.count = groups - 1;
     for (int t = 0; t < groups - 1; t++) sp.s[t] = splitters[t];
