@@ -77,7 +77,8 @@ void free_lms_side(kiss_hip_ctx *ctx)
     free_tied(ctx);
     void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
                      (void **)&ctx->posB, (void **)&ctx->lms_sorted_far,
-                     (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp};
+                     (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp,
+                     (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist, (void **)&ctx->rx_ctl};
     for (void **p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -193,6 +194,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         ctx->stats.ms_place = ms[3];
         ctx->stats.ms_induce = ms[4];
         (void)hipEventElapsedTime(&ctx->stats.ms_total, ev[0], ev[6]);
+        rc = kiss_radix_check(ctx);
         break;
     }
     if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
@@ -229,7 +231,17 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         ALLOC(lmsC, m_cap);
         ALLOC(tile_hist, ctx->tile_hist_cap);
         ALLOC(scan_tmp, ctx->scan_tmp_cap);
+        ctx->rx_tiles_cap = m_cap / 16384 + 2;
+        ALLOC(rx_desc, 256 * ctx->rx_tiles_cap);
+        ALLOC(rx_ghist, 256 * 12);
+        ALLOC(rx_ctl, 4);
 #undef ALLOC
+        // descriptors carry the epoch of the pass that wrote them: cleared once, never again
+        if (hipMemset(ctx->rx_desc, 0, 256 * ctx->rx_tiles_cap * sizeof(uint64_t)) != hipSuccess ||
+            hipMemset(ctx->rx_ctl, 0, 4 * sizeof(uint32_t)) != hipSuccess)
+            rc = KISS_HIP_E_HIP;
+        ctx->rx_epoch = 0;
+        ctx->rx_ticket_base = 0;
     } while (0);
     ctx->lms_bytes = ctx->ws_bytes - before;
     if (rc) return rc;
@@ -476,7 +488,7 @@ int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, 
     rb.seg[0] = rb.seg[1] = nullptr;
     int res = 0;
     KTRY(kiss_radix_sort(ctx, rb, count, key_lo_bit, 0, &res));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_radix_check(ctx));
     KCHECK(hipMemcpy(keys, rb.key[res], count * 8, hipMemcpyDeviceToHost));
     KCHECK(hipMemcpy(pos, rb.pos[res], count * 4, hipMemcpyDeviceToHost));
     return KISS_HIP_OK;

@@ -68,6 +68,11 @@ struct kiss_hip_ctx {
     // radix / scan scratch
     uint32_t *tile_hist = nullptr; // 256 x tiles (+1)
     uint64_t tile_hist_cap = 0;
+    // one-sweep radix passes (radix.hip): look-back descriptors, digit histograms of all passes, [ticket, error]
+    uint64_t *rx_desc = nullptr;
+    uint32_t *rx_ghist = nullptr, *rx_ctl = nullptr;
+    uint64_t rx_tiles_cap = 0, rx_epoch = 0;
+    uint32_t rx_ticket_base = 0;
     uint64_t *scan_tmp = nullptr;  // block sums for scans
     uint64_t scan_tmp_cap = 0;
     // induce
@@ -127,6 +132,7 @@ struct RadixBufs {
     uint32_t *pos[2];
 };
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
+int kiss_radix_check(kiss_hip_ctx *ctx); // synchronises; KISS_HIP_E_INTERNAL if a look-back wait ran out
 // k-ordered LMS sort of the far suffixes -> ctx->lms_sorted_far
 int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // kiss_lms_sort in exact mode gives up (no output) once suffixes still tie after this many bases

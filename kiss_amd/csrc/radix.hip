@@ -9,6 +9,7 @@
 // ascending text position order the k-ordered LMS contract needs
 // (reference tie-break `i < j`, include/biovoltron/algo/sort/kiss1_core.hpp:131-133).
 #include "kiss_internal.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -83,11 +84,139 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist(const uint64_t *__res
     }
 }
 
+// ---- one-sweep form (Adinets & Merrill): the digit histograms of ALL passes come from one read of the input
+// (they do not depend on the order of the items), and a scatter tile learns the number of items with its digit in
+// earlier tiles by decoupled look-back instead of from a per-tile histogram pass + matrix scan.
+// Descriptor word of (tile, digit): [63:62] state (1 = this tile's count, 2 = inclusive prefix over tiles 0..t),
+// [61:32] epoch of the pass (stale words of earlier passes read as "not there yet", no clearing), [31:0] value.
+// Forward progress: tiles take their number from an atomic ticket, so a tile only ever waits for tiles that started
+// before it; the wait is bounded (RX_SPIN_LIMIT polls) and flags an error instead of hanging.
+constexpr int RX_MAX_PASSES = 12;
+constexpr uint32_t RX_SPIN_LIMIT = 1u << 24;
+constexpr uint32_t RX_HIST_LDS_WORDS = 16384; // 64 KiB of histogram copies (the default dynamic-LDS limit)
+
+template <bool HAS_SEG>
+__global__ __launch_bounds__(RX_THREADS) void k_radix_hist_all(const uint64_t *__restrict__ key,
+                                                              const uint32_t *__restrict__ seg, uint64_t count,
+                                                              int key_shift0, int n_key, int n_seg,
+                                                              uint32_t *__restrict__ ghist)
+{
+    // `copies` private histograms of np x 256 bins (dynamic LDS); waves w, w + copies, ... share one
+    extern __shared__ uint32_t h[];
+    const int np = n_key + n_seg;
+    const uint32_t per = (uint32_t)np * 256u;
+    const uint32_t copies = RX_HIST_LDS_WORDS / per < (uint32_t)RX_WAVES ? RX_HIST_LDS_WORDS / per : (uint32_t)RX_WAVES;
+    for (uint32_t i = threadIdx.x; i < copies * per; i += RX_THREADS) h[i] = 0;
+    __syncthreads();
+    uint32_t *mine = h + ((threadIdx.x >> 6) % copies) * per;
+    const uint64_t base = (uint64_t)blockIdx.x * RX_TILE + threadIdx.x;
+    // Neighbouring items often carry the same digit (segment ids of a sorted list, keys inside a repeat): the first
+    // lane of every run of equal digits adds the run length, instead of 64 lanes colliding on one LDS word.
+    auto add_runs = [&](uint32_t *bins, uint32_t d, bool valid, uint32_t nvalid) {
+        if (!HAS_SEG) { // unsorted input (round 0): digits are spread, plain adds are cheaper
+            if (valid) atomicAdd(&bins[d], 1u);
+            return;
+        }
+        const uint32_t prev = __shfl_up(d, 1, 64);
+        const bool head = valid && (lane_id() == 0 || d != prev);
+        const uint64_t hm = __ballot(head);
+        if (head) {
+            const uint64_t above = lane_id() == 63 ? 0ull : (hm >> (lane_id() + 1));
+            const uint32_t next = above ? lane_id() + 1u + (uint32_t)(__ffsll((unsigned long long)above) - 1) : nvalid;
+            atomicAdd(&bins[d], next - lane_id());
+        }
+    };
+#pragma unroll 2
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const uint64_t g = base + (uint64_t)j * RX_THREADS;
+        const bool valid = g < count;
+        const uint32_t nvalid = (uint32_t)__popcll(__ballot(valid)); // valid lanes are the low ones
+        if (nvalid == 0) continue;
+        const uint64_t k = valid ? key[g] : 0ull;
+        for (int p = 0; p < n_key; p++) add_runs(mine + p * 256, (uint32_t)(k >> (key_shift0 + 8 * p)) & 255u, valid, nvalid);
+        if (HAS_SEG) {
+            const uint32_t sg = valid ? seg[g] : 0u;
+            for (int q = 0; q < n_seg; q++) add_runs(mine + (n_key + q) * 256, (sg >> (8 * q)) & 255u, valid, nvalid);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < per; i += RX_THREADS) {
+        uint32_t t = 0;
+        for (uint32_t c = 0; c < copies; c++) t += h[c * per + i];
+        if (t) atomicAdd(&ghist[i], t);
+    }
+}
+
+// ghist[p][0..255] -> exclusive prefix in place (one workgroup of 256 per pass)
+__global__ __launch_bounds__(256) void k_radix_digit_bases(uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t ws[4];
+    uint32_t *g = ghist + (uint64_t)blockIdx.x * 256;
+    const uint32_t v = g[threadIdx.x];
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((int)lane_id() >= d) inc += o;
+    }
+    if (lane_id() == 63) ws[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t pre = inc - v;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += ws[w];
+    g[threadIdx.x] = pre;
+}
+
+__device__ __forceinline__ uint64_t rx_desc_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rx_desc_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// number of items with digit d in tiles 0 .. tile-1; publishes this tile's count / inclusive prefix
+__device__ __forceinline__ uint32_t rx_lookback(uint64_t *__restrict__ desc, uint32_t tile, uint32_t d, uint32_t tot,
+                                                uint64_t epoch, uint32_t *__restrict__ err)
+{
+    const uint64_t tag = (epoch & 0x3FFFFFFFull) << 32;
+    uint64_t *mine = desc + (uint64_t)tile * 256 + d;
+    if (tile == 0) {
+        rx_desc_store(mine, (2ull << 62) | tag | tot);
+        return 0;
+    }
+    rx_desc_store(mine, (1ull << 62) | tag | tot);
+    uint32_t excl = 0;
+    uint32_t t = tile;
+    while (t > 0) {
+        t--;
+        const uint64_t *q = desc + (uint64_t)t * 256 + d;
+        uint64_t v = rx_desc_load(q);
+        uint32_t spins = 0;
+        while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
+            if (++spins > RX_SPIN_LIMIT) {
+                *err = 1; // a predecessor never published: give up with what we have (writes stay in range)
+                rx_desc_store(mine, (2ull << 62) | tag | (excl + tot));
+                return excl;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = rx_desc_load(q);
+        }
+        excl += (uint32_t)v;
+        if ((v >> 62) == 2) break;
+    }
+    rx_desc_store(mine, (2ull << 62) | tag | (excl + tot));
+    return excl;
+}
+
 // Scatter.  LDS holds ONE 128 KiB staging buffer that the key, position and segment columns pass through in
 // turn (each column is reordered locally and leaves as coalesced per-digit runs): one workgroup of 16 waves per CU.
 // (Measured: 8192-item tiles with two workgroups per CU are 18 % slower -- run length per digit matters more
 //  than overlap between workgroups.)
-template <int SRC, bool HAS_SEG>
+// ONE = false: tile_off holds the scanned per-(tile, digit) offsets (histogram pass + matrix scan ran before);
+// ONE = true : tile_off holds the 256 global digit bases of this pass, tiles are numbered by ticket and find their
+//              offsets by look-back over `desc`
+template <int SRC, bool HAS_SEG, bool ONE>
 __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ key_in,
                                                                 const uint32_t *__restrict__ seg_in,
                                                                 const uint32_t *__restrict__ pos_in,
@@ -95,18 +224,26 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
                                                                 uint32_t *__restrict__ seg_out,
                                                                 uint32_t *__restrict__ pos_out, uint64_t count,
                                                                 int shift, const uint32_t *__restrict__ tile_off,
-                                                                uint64_t tiles)
+                                                                uint64_t tiles, uint64_t *__restrict__ desc,
+                                                                uint32_t *__restrict__ ctl, uint32_t ticket_base,
+                                                                uint64_t epoch)
 {
     __shared__ uint64_t stage64[RX_TILE];
     __shared__ uint32_t wcnt[RX_WAVES][256];
     __shared__ uint32_t gbase[256];
     __shared__ uint32_t wsum[RX_WAVES + 1];
+    __shared__ uint32_t s_tile;
     uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage64);
     (void)tiles;
 
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
-    const uint64_t tile_base = (uint64_t)blockIdx.x * RX_TILE;
+    if (ONE) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u) - ticket_base;
+        __syncthreads();
+    }
+    const uint32_t tile = ONE ? s_tile : blockIdx.x;
+    const uint64_t tile_base = (uint64_t)tile * RX_TILE;
     const uint32_t tile_count = (uint32_t)((count - tile_base) < (uint64_t)RX_TILE ? (count - tile_base) : RX_TILE);
 
     if (threadIdx.x < 256) {
@@ -179,7 +316,8 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
         if (dig) {
             uint32_t start = inc - tot;
             for (int w = 0; w < wave; w++) start += wsum[w];
-            gbase[d] = tile_off[(uint64_t)blockIdx.x * 256 + d] - start;
+            if (ONE) gbase[d] = tile_off[d] + rx_lookback(desc, tile, d, tot, epoch, &ctl[1]) - start;
+            else gbase[d] = tile_off[(uint64_t)tile * 256 + d] - start;
             uint32_t run = start;
 #pragma unroll
             for (int w = 0; w < RX_WAVES; w++) {
@@ -348,28 +486,86 @@ int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shi
     KTRY(radix_offsets(ctx, tiles));
     {
         KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
-        hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG, false>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
                            b.key[src], b.seg[src], b.pos[src], b.key[dst], b.seg[dst], b.pos[dst], count, shift,
-                           ctx->tile_hist, tiles);
+                           ctx->tile_hist, tiles, nullptr, nullptr, 0u, 0ull);
         KCHECK(hipGetLastError());
     }
     return KISS_HIP_OK;
 }
 
+// one-sweep pass p (digit bases already in rx_ghist[p])
+template <int SRC, bool HAS_SEG>
+int radix_pass_one(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift, int p)
+{
+    const uint64_t tiles = div_up(count, RX_TILE);
+    const int dst = src ^ 1;
+    KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
+    ctx->rx_epoch++;
+    hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG, true>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
+                       b.key[src], b.seg[src], b.pos[src], b.key[dst], b.seg[dst], b.pos[dst], count, shift,
+                       ctx->rx_ghist + 256 * p, tiles, ctx->rx_desc, ctx->rx_ctl, ctx->rx_ticket_base, ctx->rx_epoch);
+    KCHECK(hipGetLastError());
+    ctx->rx_ticket_base += (uint32_t)tiles;
+    return KISS_HIP_OK;
+}
+
 } // namespace
+
+// after a stream synchronisation: did any look-back give up?  (never observed; the wait is bounded so that a bug
+// shows up as an error code instead of a hung GPU)
+int kiss_radix_check(kiss_hip_ctx *ctx)
+{
+    if (!ctx->rx_ctl) return KISS_HIP_OK;
+    uint32_t err = 0;
+    KCHECK(hipMemcpyAsync(&err, ctx->rx_ctl + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    if (err) {
+        (void)hipMemsetAsync(ctx->rx_ctl + 1, 0, sizeof(uint32_t), ctx->stream);
+        return KINTERNAL();
+    }
+    return KISS_HIP_OK;
+}
 
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx)
 {
     int cur = 0;
     if (count > 1) {
         const bool has_seg = seg_bits > 0;
-        for (int shift = key_lo_bit & ~7; shift < 64; shift += 8) {
-            if (has_seg) KTRY((radix_pass<0, true>(ctx, b, cur, count, shift)));
-            else KTRY((radix_pass<0, false>(ctx, b, cur, count, shift)));
+        const int shift0 = key_lo_bit & ~7;
+        const int n_key = (64 - shift0) / 8, n_seg = (seg_bits + 7) / 8;
+        const uint64_t tiles = div_up(count, RX_TILE);
+        static const bool no_one = getenv("KISS_HIP_NO_ONESWEEP") != nullptr; // measurement hook
+        const bool one = !no_one && ctx->rx_desc && tiles >= 2 && tiles <= ctx->rx_tiles_cap && n_key + n_seg <= RX_MAX_PASSES;
+        if (one) {
+            KTimer t(ctx, KISS_HIP_K_RADIX_HIST, count);
+            KTRY(kiss_zero_u32(ctx, ctx->rx_ghist, 256ull * (uint64_t)(n_key + n_seg)));
+            const uint32_t per = 256u * (uint32_t)(n_key + n_seg);
+            const uint32_t copies = RX_HIST_LDS_WORDS / per < (uint32_t)RX_WAVES ? RX_HIST_LDS_WORDS / per : (uint32_t)RX_WAVES;
+            const size_t hist_lds = (size_t)copies * per * sizeof(uint32_t);
+            if (has_seg)
+                hipLaunchKernelGGL((k_radix_hist_all<true>), dim3((unsigned)tiles), dim3(RX_THREADS), hist_lds, ctx->stream, b.key[0],
+                                   b.seg[0], count, shift0, n_key, n_seg, ctx->rx_ghist);
+            else
+                hipLaunchKernelGGL((k_radix_hist_all<false>), dim3((unsigned)tiles), dim3(RX_THREADS), hist_lds, ctx->stream, b.key[0],
+                                   nullptr, count, shift0, n_key, n_seg, ctx->rx_ghist);
+            hipLaunchKernelGGL(k_radix_digit_bases, dim3((unsigned)(n_key + n_seg)), dim3(256), 0, ctx->stream, ctx->rx_ghist);
+            KCHECK(hipGetLastError());
+        }
+        int p = 0;
+        for (int shift = shift0; shift < 64; shift += 8, p++) {
+            if (one) {
+                if (has_seg) KTRY((radix_pass_one<0, true>(ctx, b, cur, count, shift, p)));
+                else KTRY((radix_pass_one<0, false>(ctx, b, cur, count, shift, p)));
+            } else {
+                if (has_seg) KTRY((radix_pass<0, true>(ctx, b, cur, count, shift)));
+                else KTRY((radix_pass<0, false>(ctx, b, cur, count, shift)));
+            }
             cur ^= 1;
         }
-        for (int shift = 0; shift < seg_bits; shift += 8) {
-            KTRY((radix_pass<1, true>(ctx, b, cur, count, shift)));
+        for (int shift = 0; shift < seg_bits; shift += 8, p++) {
+            if (one) KTRY((radix_pass_one<1, true>(ctx, b, cur, count, shift, p)));
+            else KTRY((radix_pass<1, true>(ctx, b, cur, count, shift)));
             cur ^= 1;
         }
     }

@@ -132,8 +132,7 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
         KTRY(kiss_radix_sort(ctx, rb, count, 64, 8, &res));
         if (res != 1) return KINTERNAL();
     }
-    KCHECK(hipStreamSynchronize(ctx->stream));
-    return KISS_HIP_OK;
+    return kiss_radix_check(ctx);
 }
 
 int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, uint64_t n,
@@ -152,7 +151,7 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     KTRY(kiss_lms_sort(ctx, n, k, depth_of(n, k)));
     if (count)
         KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_radix_check(ctx));
     ktimer_collect(ctx);
     return KISS_HIP_OK;
 }
@@ -178,7 +177,7 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     const uint64_t depth = depth_of(n, k);
     KTRY(kiss_place_lms(ctx, n, k, depth));
     KTRY(kiss_induce(ctx, n, d_SA));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_radix_check(ctx));
     ktimer_collect(ctx);
     return KISS_HIP_OK;
 }
