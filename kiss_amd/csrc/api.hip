@@ -78,7 +78,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
     void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
                      (void **)&ctx->posB, (void **)&ctx->lms_sorted_far,
                      (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp,
-                     (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist, (void **)&ctx->rx_ctl};
+                     (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist};
     for (void **p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -92,7 +92,7 @@ void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
     void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
-                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->pairs1, ctx->pairs2};
+                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->pairs1, ctx->pairs2, ctx->rx_ctl};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -234,14 +234,9 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         ctx->rx_tiles_cap = m_cap / 16384 + 2;
         ALLOC(rx_desc, 256 * ctx->rx_tiles_cap);
         ALLOC(rx_ghist, 256 * 12);
-        ALLOC(rx_ctl, 4);
 #undef ALLOC
-        // descriptors carry the epoch of the pass that wrote them: cleared once, never again
-        if (hipMemset(ctx->rx_desc, 0, 256 * ctx->rx_tiles_cap * sizeof(uint64_t)) != hipSuccess ||
-            hipMemset(ctx->rx_ctl, 0, 4 * sizeof(uint32_t)) != hipSuccess)
-            rc = KISS_HIP_E_HIP;
-        ctx->rx_epoch = 0;
-        ctx->rx_ticket_base = 0;
+        // descriptors carry the epoch of the pass that wrote them: cleared once, never again (the epoch keeps counting)
+        if (hipMemset(ctx->rx_desc, 0, 256 * ctx->rx_tiles_cap * sizeof(uint64_t)) != hipSuccess) rc = KISS_HIP_E_HIP;
     } while (0);
     ctx->lms_bytes = ctx->ws_bytes - before;
     if (rc) return rc;
@@ -354,6 +349,12 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
         ALLOC(d_counts, 16);
         ALLOC(CTX, max_n + 2);
         ALLOC(ind_counts, ctx->ind_tiles_cap);
+        ALLOC(rx_ctl, 4); // [0] radix ticket, [1] look-back error flag
+        if (hipMemset(ctx->rx_ctl, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
+
         ALLOC(d_small, 64);
         ALLOC(near_idx, ctx->near_cap);
         ALLOC(near_fin, ctx->near_cap);

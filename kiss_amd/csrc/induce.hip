@@ -53,6 +53,9 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
     return ((emitmask >> pc) & 1u) ? pc : 4u;
 }
 
+// (A single-pass form with decoupled look-back -- the one the radix scatter uses -- was measured at chm13 size:
+//  39.5 ms with 2048-item tiles, 35.0 ms with 8192-item tiles, against 31.6 ms for count + scan + scatter below:
+//  four counters per tile are too little work to hide the look-back latency.)
 // ---- pass 1: per-tile class counts ---------------------------------------------------
 __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                             uint32_t *srcC, int64_t beg, uint64_t N, int dir,
