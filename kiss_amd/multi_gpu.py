@@ -33,7 +33,14 @@ class GpuBackend:
         self.dev = S.device
         self.lib = _lib.load()
 
+    def _sync(self):
+        # The library works on its own HIP stream and takes raw pointers: everything torch / RCCL has queued for
+        # these buffers (collectives run on RCCL's streams and only order themselves against torch's current
+        # stream) must have finished before a stage call reads them.  Stage calls return synchronised.
+        self.torch.cuda.synchronize(self.dev)
+
     def classify(self, lo, hi):
+        self._sync()
         c = (ctypes.c_uint64 * 13)()
         _check(self.lib.kiss_hip_stage_classify(self.ctx._ctx, ctypes.c_void_p(self.S.data_ptr()), self.n, self.k, int(lo),
                                                 int(hi), ctypes.byref(c), None), "kiss_hip_stage_classify", self.ctx._ctx)
@@ -53,6 +60,7 @@ class GpuBackend:
         return keys, pos, int(mf.value)
 
     def key_hist(self, keys, bits):
+        self._sync()
         hist = self.torch.empty(1 << bits, dtype=self.torch.int64, device=self.dev)
         _check(self.lib.kiss_hip_stage_key_hist(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), int(keys.numel()), bits,
                                                 ctypes.c_void_p(hist.data_ptr()), None), "kiss_hip_stage_key_hist",
@@ -60,6 +68,7 @@ class GpuBackend:
         return hist
 
     def partition(self, keys, pos, bits, splitters, groups):
+        self._sync()
         torch = self.torch
         ko, po = torch.empty_like(keys), torch.empty_like(pos)
         sp = (ctypes.c_uint32 * max(1, groups - 1))(*[int(s) for s in splitters])
@@ -70,6 +79,7 @@ class GpuBackend:
         return ko, po
 
     def sort(self, keys, pos):
+        self._sync()
         out = self.torch.empty_like(pos)
         _check(self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
                                             int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()), None),
@@ -77,6 +87,7 @@ class GpuBackend:
         return out
 
     def induce(self, far_all, near_all, counts12, SA=None):
+        self._sync()
         torch = self.torch
         if SA is None:
             SA = torch.empty(self.n + 1, dtype=torch.int32, device=self.dev)
