@@ -76,7 +76,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
 {
     free_tied(ctx);
     void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
-                     (void **)&ctx->posB, (void **)&ctx->lms_sorted_far,
+                     (void **)&ctx->posB, (void **)&ctx->lms_sorted_far, (void **)&ctx->lms_ctx_far,
                      (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp,
                      (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist};
     for (void **p : ptrs)
@@ -227,6 +227,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         ALLOC(posA, m_cap);
         ALLOC(posB, m_cap);
         ALLOC(lms_sorted_far, m_cap);
+        ALLOC(lms_ctx_far, m_cap);
         ALLOC(lmsP, m_cap);
         ALLOC(lmsC, m_cap);
         ALLOC(tile_hist, ctx->tile_hist_cap);

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
             for (uint32_t idx = threadIdx.x; idx < tile_total; idx += CL_THREADS) {
                 uint64_t pos = tbase + stage[idx];
                 lms_pos[gbase + idx] = (uint32_t)pos;
-                lms_key[gbase + idx] = kiss_key32(pk, pos);
+                // first 32 bases; the 24 bits round 0 does not sort on carry the preceding 11 bases (kiss_internal.hpp)
+                lms_key[gbase + idx] = (kiss_key32(pk, pos) & ~KISS_KEY_CTX_MASK) | kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
             }
             __syncthreads();
         }

@@ -63,6 +63,7 @@ struct kiss_hip_ctx {
     uint32_t *bposA = nullptr, *bposB = nullptr, *bsegA = nullptr, *bsegB = nullptr, *bslot = nullptr;
     uint64_t *flags = nullptr;     // per active item: (survivor << 32) | surviving-head, then its exclusive scan
     uint32_t *lms_sorted_far = nullptr; // far LMS suffixes in k-order
+    uint32_t *lms_ctx_far = nullptr;    // parallel to lms_sorted_far: context word from the key payload, 0 = gather it
     uint32_t *lmsP = nullptr;      // all LMS suffixes in k-order (sentinel excluded)
     uint32_t *lmsC = nullptr;      // their context words
     // radix / scan scratch
@@ -163,17 +164,26 @@ __device__ __forceinline__ uint32_t kiss_base(const uint64_t *__restrict__ pk, u
 {
     return (uint32_t)(pk[p >> 5] >> (62u - 2u * (uint32_t)(p & 31u))) & 3u;
 }
-// context word of position v: bases v-1 (bits 1:0), v-2 (bits 3:2), ... up to 15 bases, marker bit above
-__device__ __forceinline__ uint32_t kiss_load_ctx(const uint64_t *__restrict__ pk, uint64_t v)
+// context word of position v: bases v-1 (bits 1:0), v-2 (bits 3:2), ... up to nb bases, marker bit above
+__device__ __forceinline__ uint32_t kiss_load_ctx_n(const uint64_t *__restrict__ pk, uint64_t v, uint32_t nb)
 {
-    if (v >= KISS_CTX_BASES) {
-        uint64_t k = kiss_key32(pk, v - KISS_CTX_BASES);
-        return (uint32_t)(k >> (64u - 2u * KISS_CTX_BASES)) | (1u << (2u * KISS_CTX_BASES));
+    if (v >= nb) {
+        uint64_t k = kiss_key32(pk, v - nb);
+        return (uint32_t)(k >> (64u - 2u * nb)) | (1u << (2u * nb));
     }
     if (v == 0) return KISS_EMPTY_CTX;
     uint64_t w0 = pk[0];
     return (uint32_t)(w0 >> (64u - 2u * (uint32_t)v)) | (1u << (2u * (uint32_t)v));
 }
+__device__ __forceinline__ uint32_t kiss_load_ctx(const uint64_t *__restrict__ pk, uint64_t v)
+{
+    return kiss_load_ctx_n(pk, v, KISS_CTX_BASES);
+}
+// Round 0 of the LMS sort orders by the first 20 bases = key bits [24, 64).  The low 24 bits of the key emitted by
+// the classification carry a short context word instead (11 bases + marker): a suffix that round 0 already makes
+// unique (82 % on genome-like text) gets its context word without the random text gather of the placement step.
+constexpr uint32_t KISS_KEY_CTX_BASES = 11;
+constexpr uint64_t KISS_KEY_CTX_MASK = 0xFFFFFFull;
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's
 // outstanding global stores (vmcnt), so a store burst overlaps the next LDS staging step
 __device__ __forceinline__ void lds_barrier()

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_count(const uint64_t *__restr
 }
 
 // out: retired items land in out[slot] (nullptr: they already are where they belong);
-// isa (optional): inverse array, isa[position] = slot for every retired item
+// isa (optional): inverse array, isa[position] = slot for every retired item;
+// octx (optional, round 0 only): context word per slot from the key payload, 0 for slots still tied
 template <int SRC, bool HAS_SLOT>
 __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__restrict__ key,
                                                           const uint32_t *__restrict__ seg,
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           const uint64_t *__restrict__ tex, // exclusive scan of tcnt
                                                           uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
                                                           uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
-                                                          uint32_t *__restrict__ out, uint32_t *__restrict__ isa)
+                                                          uint32_t *__restrict__ out, uint32_t *__restrict__ isa,
+                                                          uint32_t *__restrict__ octx)
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -322,9 +324,13 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             nslot[ni] = sl;
             nseg[ni] = sid;
             if ((fl >> (2 * j)) & 2u) nsegstart[sid] = ni;
+            if (octx) octx[sl] = 0; // tied so far: its context word is gathered at placement
         } else {
             if (out) out[sl] = p;
             if (isa) isa[p] = sl;
+            if constexpr (SRC != FC_HEADS) {
+                if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
+            }
         }
     }
 }
@@ -367,13 +373,13 @@ int fc_read_total(kiss_hip_ctx *ctx, const uint64_t *d_total, uint64_t *tot)
 template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
-               uint32_t *nsegstart, uint32_t *out, uint32_t *isa)
+               uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr)
 {
     const uint64_t tiles = div_up(count, FC_TILE);
     const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
     KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
     hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
-                       pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa);
+                       pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa, octx);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -437,6 +443,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     if (m_far == 1) {
         KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, ctx->lms_pos, sizeof(uint32_t), hipMemcpyDeviceToDevice,
                               ctx->stream));
+        KTRY(kiss_zero_u32(ctx, ctx->lms_ctx_far, 1));
         return KISS_HIP_OK;
     }
     uint32_t *d_nbig = ctx->d_small + 8;
@@ -477,7 +484,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint64_t *F1 = ctx->flags;
     uint64_t *F2 = ctx->flags + ctx->t_cap;
     KTRY((fc_compact<FC_KEY, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
-                                   ctx->lms_sorted_far, nullptr)));
+                                   ctx->lms_sorted_far, nullptr, ctx->lms_ctx_far)));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     if (dbg)

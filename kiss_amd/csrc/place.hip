@@ -7,8 +7,9 @@
 //    padding, kiss1_core.hpp:41-83 + structs.hpp:175-184, then cmp), and among themselves pairwise.
 //    Every far suffix precedes every near-end suffix in text position, so cmp(far, near) is monotone
 //    over the far list and the insertion point is unique.
-// 2. Merge far + near-end into the final list lmsP and gather the context word (the <= 15 bases that
-//    precede each suffix) the induction sweeps consume instead of random text reads.
+// 2. Merge far + near-end into the final list lmsP and attach the context word (the bases that precede each
+//    suffix) the induction sweeps consume instead of random text reads: 11 bases from the payload of the
+//    classification key for suffixes that round 0 of the sort made unique, a 15-base text gather for the rest.
 #include "kiss_internal.hpp"
 
 namespace {
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_order(const uint64_t *__res
 
 // merged list + context words.  near_sidx: insertion indexes sorted ascending (E entries)
 __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__restrict__ pk,
-                                                         const uint32_t *__restrict__ far_sorted, uint64_t m_far,
+                                                         const uint32_t *__restrict__ far_sorted,
+                                                         const uint32_t *__restrict__ far_ctx, uint64_t m_far,
                                                          const uint32_t *__restrict__ near_sidx, uint32_t E,
                                                          uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC)
 {
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
         else hi = mid;
     }
     uint32_t x = far_sorted[i];
+    uint32_t c = far_ctx[i]; // from the key payload when round 0 already made the suffix unique, else 0
+    if (c == 0) c = kiss_load_ctx(pk, x);
     lmsP[i + lo] = x;
-    lmsC[i + lo] = kiss_load_ctx(pk, x);
+    lmsC[i + lo] = c;
 }
 
 __global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__restrict__ pk,
@@ -172,13 +176,14 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         KCHECK(hipStreamSynchronize(ctx->stream)); // idx goes out of scope
         if (m_far)
             hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0,
-                               ctx->stream, ctx->pk, ctx->lms_sorted_far, m_far, ctx->near_pos, E, ctx->lmsP,
-                               ctx->lmsC);
+                               ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_pos, E,
+                               ctx->lmsP, ctx->lmsC);
         hipLaunchKernelGGL(k_merge_near, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
                            ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
     } else {
         hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
-                           ctx->pk, ctx->lms_sorted_far, m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP, ctx->lmsC);
+                           ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP,
+                           ctx->lmsC);
     }
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;

@@ -166,8 +166,10 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     const uint64_t m = m_far + near_count;
     if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
-    if (m_far)
+    if (m_far) {
         KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        KTRY(kiss_zero_u32(ctx, ctx->lms_ctx_far, m_far)); // the pieces arrive without context words: gather them all
+    }
     if (near_count) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
         KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     for (int i = 0; i < 12; i++) ctx->counts[i] = counts12[i];
