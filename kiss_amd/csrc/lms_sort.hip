@@ -50,6 +50,26 @@ __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint6
         if (depth && d >= depth) return i_before_j;
         uint64_t qi = pi + d, qj = pj + d;
         if (qi >= n && qj >= n) return i_before_j; // both ran off the text (does not happen for two LMS suffixes)
+        if (qi + 96 < n && qj + 96 < n && (!depth || depth - d >= 128)) {
+            // 128 bases per step: the ten word loads are independent, so one round trip to memory covers four
+            // 32-base compares (the walk through a long repeat is a chain of dependent loads otherwise)
+            const uint64_t *wi = pk + (qi >> 5), *wj = pk + (qj >> 5);
+            const uint32_t si = 2u * (uint32_t)(qi & 31u), sj = 2u * (uint32_t)(qj & 31u);
+            uint64_t a[5], b[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                a[t] = wi[t];
+                b[t] = wj[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));
+                const uint64_t kj = (b[t] << sj) | ((b[t + 1] >> 1) >> (63u - sj));
+                if (ki != kj) return ki < kj;
+            }
+            d += 128;
+            continue;
+        }
         uint64_t ki = qi < n ? kiss_key32(pk, qi) : 0ull;
         uint64_t kj = qj < n ? kiss_key32(pk, qj) : 0ull;
         if (depth && depth - d < 32) {
@@ -101,15 +121,24 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           uint32_t *__restrict__ out, uint64_t *__restrict__ big,
                                                           uint32_t *__restrict__ nbig)
 {
-    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    bool isbig = false;
-    if (i < count) {
-        uint32_t sg = seg[i];
-        uint32_t a = segstart[sg], b = segstart[sg + 1];
-        if (b - a <= small_seg) {
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    const bool valid = i < count;
+    uint32_t a = 0, b = 0;
+    if (valid) {
+        const uint32_t sg = seg[i];
+        a = segstart[sg];
+        b = segstart[sg + 1];
+    }
+    const bool small = valid && (b - a <= small_seg);
+    // a pair (by far the most common tied segment: two copies of a repeat) is compared once: its first member walks
+    // the two suffixes, the second one -- the next lane -- takes the opposite rank
+    const bool second_in_wave = small && (b - a == 2) && ((uint32_t)i == a + 1) && lane_id() > 0;
+    uint32_t r = 0;
+    uint64_t pi = 0;
+    if (small) {
+        pi = pos[i];
+        if (!second_in_wave) {
             const uint64_t ki = key[i];
-            const uint64_t pi = pos[i];
-            uint32_t r = 0;
             bool sorted = false;
             if (b - a >= 3) { // adjacent pairs all in order -> already sorted
                 sorted = true;
@@ -127,14 +156,16 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                     r += jless ? 1u : 0u;
                 }
             }
-            out[slot[a + r]] = (uint32_t)pi;
-            big[i] = 0;
-        } else {
-            isbig = true;
-            big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
         }
     }
-    (void)isbig;
+    const uint32_t r_prev = __shfl_up(r, 1, 64);
+    if (second_in_wave) r = 1u - r_prev;
+    if (small) {
+        out[slot[a + r]] = (uint32_t)pi;
+        big[i] = 0;
+    } else if (valid) {
+        big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
+    }
     (void)nbig; // the number of big-segment items comes out of the flag scan (one address hit by every wave's
                 // atomicAdd cost more than the rest of this kernel)
 }
