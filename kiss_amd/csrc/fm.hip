@@ -19,6 +19,10 @@
 namespace {
 
 constexpr int FM_THREADS = 256;
+// Patterns with more hits than this (tandem repeats: up to ~10^6 occurrences) are located by a whole workgroup;
+// with one lane per pattern the longest one alone set the kernel time.
+constexpr uint32_t FM_HEAVY = 256;
+constexpr int FMH_THREADS = 512;
 
 struct FmiD {
     uint64_t N;
@@ -81,7 +85,8 @@ __device__ __forceinline__ uint32_t fm_b_occ(const FmiD &f, uint64_t i)
 // ---- backward search: one lane per pattern -------------------------------------------------------
 __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *__restrict__ pat, uint32_t L, uint64_t Q,
                                                         uint32_t *__restrict__ beg_out, uint32_t *__restrict__ end_out,
-                                                        uint64_t *__restrict__ cap /* hits + 4 per pattern */)
+                                                        uint64_t *__restrict__ cap /* hits + 4 per pattern */,
+                                                        uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ nheavy)
 {
     uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
     if (q >= Q) return;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
     beg_out[q] = (uint32_t)beg;
     end_out[q] = (uint32_t)end;
     cap[q] = (end - beg) + 4;
+    if (end - beg > FM_HEAVY) heavy_list[atomicAdd(nheavy, 1u)] = (uint32_t)q; // located by a workgroup (order irrelevant)
 }
 
 // ---- locate: the reference's FIFO breadth-first walk, one lane per pattern ------------------------------
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
     unsigned long long got = 0, sum = 0;
     if (q < Q) {
         const uint64_t b0 = beg_in[q], e0 = end_in[q];
-        const uint64_t want = e0 - b0;
+        const uint64_t want = e0 - b0 > FM_HEAVY ? 0 : e0 - b0; // heavy patterns: k_fm_locate_heavy
         const uint64_t base = cap_index[q];
         const uint64_t capq = want + 4;
         uint2 *cur = frontier0 + base, *nxt = frontier1 + base;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
             nxt = tmp;
             ncur = nn < capq ? nn : capq;
         }
-        got_out[q] = got < capq ? got : capq;
+        if (e0 - b0 <= FM_HEAVY) got_out[q] = got < capq ? got : capq;
         if (got > capq) got = capq; // can not happen; keeps totals consistent with the buffers
     }
     // wave-level reduction of (hits, checksum), one atomic pair per wave
@@ -174,17 +180,145 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
     }
 }
 
-__global__ __launch_bounds__(FM_THREADS) void k_fm_gather_offsets(const uint32_t *__restrict__ scratch,
-                                                                 const uint64_t *__restrict__ cap_index,
-                                                                 const uint64_t *__restrict__ got,
-                                                                 const uint64_t *__restrict__ off_index, uint64_t Q,
-                                                                 uint32_t *__restrict__ offsets, uint64_t capacity)
+// ---- locate for one heavy pattern per workgroup ------------------------------------------------------------
+// Same breadth-first walk and the same output order; a level has at most 4^depth <= 64 ranges, so wave 0 handles
+// the ranges (one lane each: sampled-row counts, the stop rule, the children) and then all threads write the
+// level's offsets -- output o belongs to the range whose prefix count covers it.
+__global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const uint32_t *__restrict__ beg_in,
+                                                                const uint32_t *__restrict__ end_in,
+                                                                const uint32_t *__restrict__ heavy_list,
+                                                                const uint64_t *__restrict__ cap_index,
+                                                                uint32_t *__restrict__ out, uint64_t *__restrict__ got_out,
+                                                                unsigned long long *__restrict__ totals)
 {
-    uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
-    if (q >= Q) return;
-    const uint64_t src = cap_index[q], dst = off_index[q], g = got[q];
-    for (uint64_t i = 0; i < g; i++)
-        if (dst + i < capacity) offsets[dst + i] = scratch[src + i];
+    __shared__ uint2 fr[2][64];
+    __shared__ uint32_t d_ob[64], d_pre[65];
+    __shared__ uint32_t s_n, s_np, s_total, s_stop;
+    __shared__ unsigned long long s_sum[FMH_THREADS / 64];
+    const uint32_t q = heavy_list[blockIdx.x];
+    const uint64_t b0 = beg_in[q], e0 = end_in[q];
+    const uint64_t want = e0 - b0, base = cap_index[q], capq = want + 4;
+    if (threadIdx.x == 0) {
+        fr[0][0] = make_uint2((uint32_t)b0, (uint32_t)e0);
+        s_n = 1;
+    }
+    __syncthreads();
+    uint64_t got = 0; // uniform
+    unsigned long long sum = 0;
+    int cur = 0;
+    for (int dep = 0; dep < 4; dep++) {
+        const uint32_t ncur = s_n;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t t = threadIdx.x;
+            const bool valid = t < ncur;
+            uint64_t cb = 0, ce = 0;
+            uint32_t ob = 0, cnt = 0;
+            if (valid) {
+                const uint2 r = fr[cur][t];
+                cb = r.x;
+                ce = r.y;
+                ob = fm_b_occ(f, cb);
+                cnt = fm_b_occ(f, ce) - ob;
+            }
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if ((int)t >= d) inc += o;
+            }
+            const uint32_t excl = inc - cnt;
+            const bool proc = valid && (got + excl < want); // the reference checks `got >= want` before every range
+            const uint64_t pm = __ballot(proc);
+            const uint32_t np = (uint32_t)__popcll(pm);  // processed ranges form a prefix
+            const uint32_t totp = np ? __shfl(inc, (int)np - 1, 64) : 0u;
+            if (proc) {
+                d_ob[t] = ob;
+                d_pre[t] = excl;
+            }
+            // children
+            uint2 ch[4];
+            uint32_t nch = 0;
+            if (proc && dep + 1 < 4) {
+                if (cb + 1 == ce) {
+                    const uint64_t nb = fm_lf(f, fm_bwt(f, cb), cb);
+                    ch[nch++] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
+                } else {
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) {
+                        const uint64_t nb = fm_lf(f, c, cb), ne = fm_lf(f, c, ce);
+                        if (nb != ne) ch[nch++] = make_uint2((uint32_t)nb, (uint32_t)ne);
+                    }
+                }
+            }
+            uint32_t cinc = nch;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(cinc, d, 64);
+                if ((int)t >= d) cinc += o;
+            }
+            const uint32_t cex = cinc - nch;
+            for (uint32_t j = 0; j < nch; j++)
+                if (cex + j < 64) fr[cur ^ 1][cex + j] = ch[j]; // <= 4^(dep+1) <= 64 children
+            const uint32_t ctot = __shfl(cinc, 63, 64);
+            if (t == 0) {
+                d_pre[np] = totp;
+                s_np = np;
+                s_n = ctot < 64 ? ctot : 64;
+                s_total = totp;
+                s_stop = (np < ncur) ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_total, np = s_np;
+        for (uint32_t o = threadIdx.x; o < total; o += FMH_THREADS) {
+            uint32_t lo = 0, hi = np; // last processed range t with d_pre[t] <= o (ranges without sampled rows tie: the last one wins)
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (d_pre[mid] <= o) lo = mid;
+                else hi = mid;
+            }
+            const uint32_t v = f.sa[d_ob[lo] + (o - d_pre[lo])] + (uint32_t)dep;
+            const uint64_t idx = got + o;
+            if (idx < capq) out[base + idx] = v;
+            sum += v;
+        }
+        got += total;
+        const bool stop = s_stop != 0;
+        cur ^= 1;
+        __syncthreads();
+        if (stop) break;
+    }
+    // totals
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane_id() == 0) s_sum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (int w = 0; w < FMH_THREADS / 64; w++) s += s_sum[w];
+        const uint64_t g = got < capq ? got : capq;
+        got_out[q] = g;
+        atomicAdd(&totals[0], (unsigned long long)g);
+        atomicAdd(&totals[1], s);
+    }
+}
+
+// offsets of all patterns, compacted: one thread per output element
+__global__ __launch_bounds__(FM_THREADS) void k_fm_gather_offsets_flat(const uint32_t *__restrict__ scratch,
+                                                                      const uint64_t *__restrict__ cap_index,
+                                                                      const uint64_t *__restrict__ off_index, uint64_t Q,
+                                                                      uint32_t *__restrict__ offsets, uint64_t capacity)
+{
+    const uint64_t o = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (o >= off_index[Q] || o >= capacity) return;
+    uint64_t lo = 0, hi = Q; // last q with off_index[q] <= o
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (off_index[mid] <= o) lo = mid;
+        else hi = mid;
+    }
+    offsets[o] = scratch[cap_index[lo] + (o - off_index[lo])];
 }
 
 __global__ void k_set_last_u64(uint64_t *arr, uint64_t idx, const uint64_t *ex, const uint64_t *vals)
@@ -338,7 +472,9 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     f.b = fmi->b;
     f.b_occ = fmi->b_occ;
 
-    DevBuf cap, capidx, got, gotidx, tot, fr0, fr1, scratch;
+    DevBuf cap, capidx, got, gotidx, tot, fr0, fr1, scratch, heavy;
+    KTRY(heavy.alloc(ctx, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
+    KTRY(kiss_zero_u32(ctx, heavy.p, 1));
     KTRY(cap.alloc(ctx, (Q + 1) * 8));
     KTRY(capidx.alloc(ctx, (Q + 1) * 8));
     KTRY(got.alloc(ctx, (Q + 1) * 8));
@@ -348,13 +484,15 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
         hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
-                           (uint64_t *)cap.p);
+                           (uint64_t *)cap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p);
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_zero_u32(ctx, (uint8_t *)cap.p + Q * 8, 2));
     KTRY(kiss_scan_u64(ctx, (const uint64_t *)cap.p, (uint64_t *)capidx.p, Q + 1));
     uint64_t total_cap = 0;
+    uint32_t nheavy = 0;
     KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipMemcpyAsync(&nheavy, heavy.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
     KTRY(fr0.alloc(ctx, total_cap * sizeof(uint2)));
     KTRY(fr1.alloc(ctx, total_cap * sizeof(uint2)));
@@ -365,14 +503,20 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
         hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
                            (const uint64_t *)capidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p, (uint32_t *)scratch.p,
                            (uint64_t *)got.p, (unsigned long long *)tot.p);
+        if (nheavy)
+            hipLaunchKernelGGL(k_fm_locate_heavy, dim3(nheavy), dim3(FMH_THREADS), 0, ctx->stream, f, beg, end,
+                               (const uint32_t *)heavy.p + 1, (const uint64_t *)capidx.p, (uint32_t *)scratch.p,
+                               (uint64_t *)got.p, (unsigned long long *)tot.p);
         KCHECK(hipGetLastError());
     }
     if (offsets && offsets_index) {
         KTRY(kiss_zero_u32(ctx, (uint8_t *)got.p + Q * 8, 2));
         KTRY(kiss_scan_u64(ctx, (const uint64_t *)got.p, offsets_index, Q + 1));
-        hipLaunchKernelGGL(k_fm_gather_offsets, dim3(grid), dim3(FM_THREADS), 0, ctx->stream,
-                           (const uint32_t *)scratch.p, (const uint64_t *)capidx.p, (const uint64_t *)got.p,
-                           offsets_index, Q, offsets, offsets_capacity);
+        const uint64_t bound = total_cap < offsets_capacity ? total_cap : offsets_capacity; // >= number of offsets
+        if (bound)
+            hipLaunchKernelGGL(k_fm_gather_offsets_flat, dim3((unsigned)div_up(bound, FM_THREADS)), dim3(FM_THREADS), 0,
+                               ctx->stream, (const uint32_t *)scratch.p, (const uint64_t *)capidx.p, offsets_index, Q, offsets,
+                               offsets_capacity);
         KCHECK(hipGetLastError());
     }
     uint64_t h[2] = {0, 0};
