@@ -95,6 +95,8 @@ void free_all(kiss_hip_ctx *ctx)
                     ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->pairs1, ctx->pairs2, ctx->rx_ctl};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : ctx->fm_pool)
+        if (p) (void)hipFree(p);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto &e : ctx->ev_pool) {
         (void)hipEventDestroy(e.a);

@@ -427,9 +427,10 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_rebase(uint32_t *a, uint64_t 
 
 struct DevBuf {
     void *p = nullptr;
+    bool pooled = false;
     ~DevBuf()
     {
-        if (p) (void)hipFree(p);
+        if (p && !pooled) (void)hipFree(p);
     }
     int alloc(kiss_hip_ctx *ctx, uint64_t bytes)
     {
@@ -439,6 +440,27 @@ struct DevBuf {
             p = nullptr;
             return KISS_HIP_E_NOMEM;
         }
+        return KISS_HIP_OK;
+    }
+    // scratch of the batched query: kept in the ctx between calls (slot = fixed role), regrown when too small --
+    // nine hipMalloc / hipFree pairs per batch cost as much as the kernels
+    int take(kiss_hip_ctx *ctx, int slot, uint64_t bytes)
+    {
+        pooled = true;
+        if (ctx->fm_pool_cap[slot] < bytes) {
+            if (ctx->fm_pool[slot]) (void)hipFree(ctx->fm_pool[slot]);
+            ctx->fm_pool[slot] = nullptr;
+            ctx->fm_pool_cap[slot] = 0;
+            const uint64_t want = bytes + bytes / 8 + 256;
+            hipError_t e = hipMalloc(&ctx->fm_pool[slot], want);
+            if (e != hipSuccess) {
+                ctx->last_hip_error = (int)e;
+                ctx->fm_pool[slot] = nullptr;
+                return KISS_HIP_E_NOMEM;
+            }
+            ctx->fm_pool_cap[slot] = want;
+        }
+        p = ctx->fm_pool[slot];
         return KISS_HIP_OK;
     }
 };
@@ -473,13 +495,13 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     f.b_occ = fmi->b_occ;
 
     DevBuf cap, capidx, got, gotidx, tot, fr0, fr1, scratch, heavy;
-    KTRY(heavy.alloc(ctx, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
+    KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
-    KTRY(cap.alloc(ctx, (Q + 1) * 8));
-    KTRY(capidx.alloc(ctx, (Q + 1) * 8));
-    KTRY(got.alloc(ctx, (Q + 1) * 8));
-    KTRY(gotidx.alloc(ctx, (Q + 1) * 8));
-    KTRY(tot.alloc(ctx, 16));
+    KTRY(cap.take(ctx, 1, (Q + 1) * 8));
+    KTRY(capidx.take(ctx, 2, (Q + 1) * 8));
+    KTRY(got.take(ctx, 3, (Q + 1) * 8));
+    KTRY(gotidx.take(ctx, 4, (Q + 1) * 8));
+    KTRY(tot.take(ctx, 5, 16));
     const unsigned grid = (unsigned)div_up(Q, FM_THREADS);
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
@@ -494,9 +516,9 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipMemcpyAsync(&nheavy, heavy.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
-    KTRY(fr0.alloc(ctx, total_cap * sizeof(uint2)));
-    KTRY(fr1.alloc(ctx, total_cap * sizeof(uint2)));
-    KTRY(scratch.alloc(ctx, total_cap * sizeof(uint32_t)));
+    KTRY(fr0.take(ctx, 6, total_cap * sizeof(uint2)));
+    KTRY(fr1.take(ctx, 7, total_cap * sizeof(uint2)));
+    KTRY(scratch.take(ctx, 8, total_cap * sizeof(uint32_t)));
     KTRY(kiss_zero_u32(ctx, tot.p, 4));
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
