@@ -781,11 +781,6 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
                                total, h0, heads);
         }
-        if (getenv("KISS_HIP_ISA_DIRECT")) { // measurement hook: the plain random scatter
-            KTimer t(ctx, KISS_HIP_K_ISA, total);
-            hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
-        } else if ((rc = kiss_isa_build(ctx, d_SA, total, isa)))
-            break;
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
         if ((rc = fc_read_total(ctx, d_total, &tot))) break;
@@ -795,6 +790,12 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffixes tied at depth %u in %llu groups\n",
                     (unsigned long long)count, (unsigned long long)total, h0, (unsigned long long)nseg);
         if (count == 0) break;
+        // the inverse suffix array is only needed when something is tied
+        if (getenv("KISS_HIP_ISA_DIRECT")) { // measurement hook: the plain random scatter
+            KTimer t(ctx, KISS_HIP_K_ISA, total);
+            hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
+        } else if ((rc = kiss_isa_build(ctx, d_SA, total, isa)))
+            break;
         if (count > ctx->m_cap || count > ctx->t_cap) { // regrow the work buffers (their contents are dead); keeps CTX, pk
             const uint64_t want = count + count / 64 + 1024;
             if (count > ctx->m_cap && (rc = kiss_lms_reserve(ctx, want))) break;
