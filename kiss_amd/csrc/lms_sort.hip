@@ -176,7 +176,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__re
                                                            const uint64_t *__restrict__ big,
                                                            const uint64_t *__restrict__ ex,
                                                            uint64_t *__restrict__ bkey, uint32_t *__restrict__ bpos,
-                                                           uint32_t *__restrict__ bseg, uint32_t *__restrict__ bslot)
+                                                           uint32_t *__restrict__ bseg, uint32_t *__restrict__ bslot,
+                                                           uint32_t *__restrict__ bsegstart)
 {
     uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= count) return;
@@ -184,11 +185,105 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__re
     if (!(f >> 32)) return;
     uint64_t e = ex[i];
     uint32_t kx = (uint32_t)(e >> 32);
+    const uint32_t sid = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
     bkey[kx] = key[i];
     bpos[kx] = pos[i];
     bslot[kx] = slot[i]; // slots stay in index order: the k-th item after the sort takes the k-th slot
-    bseg[kx] = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
+    bseg[kx] = sid;
+    if (f & 1ull) bsegstart[sid] = kx;
 }
+
+// ---- big segments: three-way split around a pivot key before any radix pass ---------------------------------
+// The members of a long tandem array stay tied round after round: most of a big segment carries ONE key (the
+// unmutated continuation of the repeat) and only the items whose 32-base window holds a mutation differ.  Sorting
+// such a segment on (segment, key) costs 8 + 3 radix passes over all of it.  Instead: pivot = the key of the
+// segment's middle item; a stable segmented partition into < pivot | == pivot | > pivot (one scan, one scatter);
+// only the < and > groups -- now segments of their own -- go through the radix sort.  The result is the same
+// (segment, key) order.  cls[i] = [key < pivot] | [key == pivot] << 32.
+__device__ __forceinline__ uint32_t pivot_class(const uint64_t *__restrict__ bkey, uint32_t a, uint32_t b, uint64_t k)
+{
+    const uint64_t pv = bkey[(a + b) >> 1];
+    return k < pv ? 0u : (k == pv ? 1u : 2u);
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_pivot_class(const uint64_t *__restrict__ bkey,
+                                                           const uint32_t *__restrict__ bseg,
+                                                           const uint32_t *__restrict__ bsegstart, uint64_t nbig,
+                                                           uint64_t *__restrict__ cls)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= nbig) return;
+    const uint32_t sid = bseg[i];
+    const uint32_t c = pivot_class(bkey, bsegstart[sid], bsegstart[sid + 1], bkey[i]);
+    cls[i] = c == 0 ? 1ull : (c == 1 ? (1ull << 32) : 0ull);
+}
+
+// ex = exclusive scan of cls, tot[0] = its grand total.  Items move inside their segment; ne[d] flags the members of
+// the < and > groups at their new place: (1 << 32) | starts-a-group.
+__global__ __launch_bounds__(LS_THREADS) void k_pivot_scatter(const uint64_t *__restrict__ bkey,
+                                                             const uint32_t *__restrict__ bpos,
+                                                             const uint32_t *__restrict__ bseg,
+                                                             const uint32_t *__restrict__ bsegstart, uint64_t nbig,
+                                                             const uint64_t *__restrict__ cls,
+                                                             const uint64_t *__restrict__ ex,
+                                                             const uint64_t *__restrict__ tot,
+                                                             uint64_t *__restrict__ okey, uint32_t *__restrict__ opos,
+                                                             uint64_t *__restrict__ ne)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= nbig) return;
+    const uint32_t sid = bseg[i];
+    const uint32_t a = bsegstart[sid], b = bsegstart[sid + 1];
+    const uint64_t ea = ex[a], eb = (uint64_t)b < nbig ? ex[b] : tot[0], ei = ex[i], ci = cls[i];
+    const uint32_t t0 = (uint32_t)eb - (uint32_t)ea, t1 = (uint32_t)(eb >> 32) - (uint32_t)(ea >> 32);
+    const uint32_t lt_before = (uint32_t)ei - (uint32_t)ea, eq_before = (uint32_t)(ei >> 32) - (uint32_t)(ea >> 32);
+    const uint32_t c = (uint32_t)ci ? 0u : ((ci >> 32) ? 1u : 2u);
+    uint32_t d;
+    if (c == 0) d = a + lt_before;
+    else if (c == 1) d = a + t0 + eq_before;
+    else d = a + t0 + t1 + ((uint32_t)i - a - lt_before - eq_before);
+    okey[d] = bkey[i];
+    opos[d] = bpos[i];
+    uint64_t f = 0;
+    if (c == 0) f = (1ull << 32) | (uint64_t)(d == a ? 1u : 0u);
+    else if (c == 2) f = (1ull << 32) | (uint64_t)(d == a + t0 + t1 ? 1u : 0u);
+    ne[d] = f;
+}
+
+// members of long groups -> compact arrays (dense group ids), remembering where they came from
+__global__ __launch_bounds__(LS_THREADS) void k_big_extract(const uint64_t *__restrict__ key,
+                                                           const uint32_t *__restrict__ pos, uint64_t count,
+                                                           const uint64_t *__restrict__ big,
+                                                           const uint64_t *__restrict__ ex, uint64_t *__restrict__ bkey,
+                                                           uint32_t *__restrict__ bpos, uint32_t *__restrict__ bseg,
+                                                           uint32_t *__restrict__ bidx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t f = big[i];
+    if (!(f >> 32)) return;
+    const uint64_t e = ex[i];
+    const uint32_t kx = (uint32_t)(e >> 32);
+    bkey[kx] = key[i];
+    bpos[kx] = pos[i];
+    bseg[kx] = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
+    bidx[kx] = (uint32_t)i;
+}
+
+// sorted on (group, key): the c-th item goes back to where the c-th extracted item came from
+__global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__restrict__ skey,
+                                                             const uint32_t *__restrict__ spos,
+                                                             const uint32_t *__restrict__ bidx, uint64_t nbig,
+                                                             uint64_t *__restrict__ okey, uint32_t *__restrict__ opos)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (c >= nbig) return;
+    const uint32_t i = bidx[c];
+    okey[i] = skey[c];
+    opos[i] = spos[c];
+}
+
+
 
 // flags[i] = (survivor << 32) | surviving_head ; keys are compared on bits [cmp_shift, 64)
 template <bool HAS_SEG>
@@ -576,26 +671,92 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                     (unsigned long long)nbig);
         }
         if (nbig == 0) break;
-        // ---- big segments: compact, radix sort on (segment, key), split, survivors go round again
+        // ---- big segments: compact, three-way split around a pivot key, radix sort of the < and > groups on
+        //      (group, key), then split where neighbours differ; survivors go round again
+        const uint64_t nbigseg = bt & 0xFFFFFFFFull;
+        uint32_t *bss = ctx->segstartB; // start of every big segment in the compact arrays (+ end entry)
+        const unsigned bgrid = (unsigned)div_up(nbig, T);
         {
             KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
             hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, Sc, count, F1, F2,
-                               ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot);
+                               ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot, bss);
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, bss + nbigseg, (uint32_t)nbig, (uint32_t *)nullptr);
             KCHECK(hipGetLastError());
         }
-        const uint64_t nbigseg = bt & 0xFFFFFFFFull;
+        uint64_t *d_ptot = (uint64_t *)(ctx->d_small + 24); // grand total of the class counts (segment ends at nbig)
+        uint64_t *NE = ctx->flags + 2 * ctx->t_cap - nbig;  // flags of the < and > members, in the tail of `flags`
+        if (2 * nbig > ctx->t_cap) NE = nullptr;            // it would overlap the scan words
+        // the first refinement round still holds the diverged copies of interspersed repeats (78 % of the items differ
+        // from their pivot at chm13 size): the split only pays from the second round on, when what is left is the
+        // long tandem arrays
+        if (off == ROUND0_BASES) NE = nullptr;
         RadixBufs bb;
-        bb.key[0] = ctx->bkeyA;
-        bb.key[1] = ctx->bkeyB;
-        bb.pos[0] = ctx->bposA;
-        bb.pos[1] = ctx->bposB;
-        bb.seg[0] = ctx->bsegA;
-        bb.seg[1] = ctx->bsegB;
-        int bres = 0;
-        KTRY(kiss_radix_sort(ctx, bb, nbig, key_lo_bit, bits_for(nbigseg), &bres));
-        ctx->stats.big_item_rounds += nbig;
-        KTRY((fused_compact<true, true>(ctx, bb.key[bres], bb.seg[bres], bb.pos[bres], ctx->bslot, nbig, 0, (int)last_round,
-                                       Pc, Sc, Gc, SSc, d_total, &tot)));
+        uint64_t *H1, *H2;
+        if (NE) {
+            {
+                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+                hipLaunchKernelGGL(k_pivot_class, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->bkeyA, ctx->bsegA, bss, nbig, F1);
+                KCHECK(hipGetLastError());
+            }
+            KTRY(kiss_scan_u64(ctx, F1, F2, nbig));
+            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, nbig, d_ptot);
+            hipLaunchKernelGGL(k_pivot_scatter, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->bkeyA, ctx->bposA, ctx->bsegA, bss,
+                               nbig, F1, F2, d_ptot, ctx->bkeyB, ctx->bposB, NE);
+            KCHECK(hipGetLastError());
+            H1 = NE;
+            H2 = F1; // the class words are dead now
+        }
+        const uint64_t *skey = ctx->bkeyB;
+        const uint32_t *spos = ctx->bposB, *sseg = ctx->bsegA;
+        if (NE) {
+            KTRY(kiss_scan_u64(ctx, H1, H2, nbig));
+            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, H1, H2, nbig, d_total);
+            uint64_t nt;
+            KTRY(read_u64(ctx, d_total, &nt));
+            const uint64_t nne = nt >> 32, ngroups = nt & 0xFFFFFFFFull;
+            if (dbg)
+                fprintf(stderr, "[kiss_hip]   big segments %llu: %llu of %llu items differ from their pivot key (%llu groups)\n",
+                        (unsigned long long)nbigseg, (unsigned long long)nne, (unsigned long long)nbig,
+                        (unsigned long long)ngroups);
+            if (nne) {
+                bb.key[0] = ctx->keyB;  // free since the round-0 compaction (K1 is keyA)
+                bb.key[1] = ctx->bkeyA; // free since the partition
+                bb.pos[0] = ctx->lmsP;  // free until the placement step
+                bb.pos[1] = ctx->lmsC;
+                bb.seg[0] = ctx->bsegB;
+                bb.seg[1] = ctx->segB;
+                uint32_t *bidx = ctx->bposA;
+                {
+                    KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+                    hipLaunchKernelGGL(k_big_extract, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->bkeyB, ctx->bposB, nbig, H1, H2,
+                                       bb.key[0], bb.pos[0], bb.seg[0], bidx);
+                    KCHECK(hipGetLastError());
+                }
+                int bres = 0;
+                KTRY(kiss_radix_sort(ctx, bb, nne, key_lo_bit, bits_for(ngroups), &bres));
+                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nne);
+                hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)div_up(nne, T)), dim3(T), 0, ctx->stream, bb.key[bres],
+                                   bb.pos[bres], bidx, nne, ctx->bkeyB, ctx->bposB);
+                KCHECK(hipGetLastError());
+            }
+            ctx->stats.big_item_rounds += nne;
+        } else { // no room for the flag words (the tied-segment arrays are nearly full): the plain radix sort
+            bb.key[0] = ctx->bkeyA;
+            bb.key[1] = ctx->bkeyB;
+            bb.pos[0] = ctx->bposA;
+            bb.pos[1] = ctx->bposB;
+            bb.seg[0] = ctx->bsegA;
+            bb.seg[1] = ctx->bsegB;
+            int bres = 0;
+            KTRY(kiss_radix_sort(ctx, bb, nbig, key_lo_bit, bits_for(nbigseg), &bres));
+            ctx->stats.big_item_rounds += nbig;
+            skey = bb.key[bres];
+            spos = bb.pos[bres];
+            sseg = bb.seg[bres];
+        }
+        KTRY((fused_compact<true, true>(ctx, skey, sseg, spos, ctx->bslot, nbig, 0, (int)last_round, Pc, Sc, Gc, SSc, d_total,
+                                       &tot)));
         count = tot >> 32;
         nseg = tot & 0xFFFFFFFFull;
         off += 32;
@@ -727,39 +888,6 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_ranks(const uint32_t *__r
     uint64_t q = (uint64_t)pos[i] + h;
     if (q > n) q = n; // cannot happen for a tied suffix (it shares h bases with another one); isa[n] = 0
     key[i] = (uint64_t)isa[q] << 32;
-}
-
-// members of long groups -> compact arrays (dense group ids), remembering where they came from
-__global__ __launch_bounds__(LS_THREADS) void k_big_extract(const uint64_t *__restrict__ key,
-                                                           const uint32_t *__restrict__ pos, uint64_t count,
-                                                           const uint64_t *__restrict__ big,
-                                                           const uint64_t *__restrict__ ex, uint64_t *__restrict__ bkey,
-                                                           uint32_t *__restrict__ bpos, uint32_t *__restrict__ bseg,
-                                                           uint32_t *__restrict__ bidx)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= count) return;
-    const uint64_t f = big[i];
-    if (!(f >> 32)) return;
-    const uint64_t e = ex[i];
-    const uint32_t kx = (uint32_t)(e >> 32);
-    bkey[kx] = key[i];
-    bpos[kx] = pos[i];
-    bseg[kx] = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
-    bidx[kx] = (uint32_t)i;
-}
-
-// sorted on (group, key): the c-th item goes back to where the c-th extracted item came from
-__global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__restrict__ skey,
-                                                             const uint32_t *__restrict__ spos,
-                                                             const uint32_t *__restrict__ bidx, uint64_t nbig,
-                                                             uint64_t *__restrict__ okey, uint32_t *__restrict__ opos)
-{
-    const uint64_t c = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (c >= nbig) return;
-    const uint32_t i = bidx[c];
-    okey[i] = skey[c];
-    opos[i] = spos[c];
 }
 
 } // namespace
