@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkiss_hip.so")
 
 KISS_HIP_OK = 0
+KISS_HIP_E_INVALID, KISS_HIP_E_NO_DEVICE, KISS_HIP_E_HIP, KISS_HIP_E_NOMEM = -1, -2, -3, -4
+KISS_HIP_E_UNSUPPORTED, KISS_HIP_E_INTERNAL, KISS_HIP_E_IO = -5, -6, -7
 ALGO_PARALLEL_SORTING = 0
 ALGO_PREFIX_DOUBLING = 1
 MAX_N = 4294967276

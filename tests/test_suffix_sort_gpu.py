@@ -208,3 +208,30 @@ def test_exact_msd_falls_back_to_doubling(ctx, oracle):
     sa2 = ctx.suffix_sort(S2, kiss_amd.K_UNBOUNDED, algo=0)
     assert ctx.stats()["refine_depth"] == 0
     assert np.array_equal(sa2, oracle.suffix_sort(S2, kiss_amd.K_UNBOUNDED))
+
+
+def test_error_codes(ctx):
+    # error behaviour of the ABI: negative status codes, never a crash, never a CPU fallback
+    import ctypes
+    import kiss_amd
+    from kiss_amd import _lib
+    lib = _lib.load()
+    S = gen.iid(1000, 1)
+    with pytest.raises(kiss_amd.KissHipError) as e:      # text longer than the workspace was created for
+        ctx.suffix_sort(np.zeros(ctx.max_n + 1, np.uint8), 256)
+    assert e.value.status == _lib.KISS_HIP_E_INVALID
+    with pytest.raises(kiss_amd.KissHipError) as e:      # unknown algorithm
+        ctx.suffix_sort(S, 256, algo=7)
+    assert e.value.status == _lib.KISS_HIP_E_INVALID
+    with pytest.raises(kiss_amd.KissHipError) as e:      # KISS2 with bounded k is not a function of its input
+        ctx.suffix_sort(S, 256, algo=1)
+    assert e.value.status == -5                           # KISS_HIP_E_UNSUPPORTED
+    SA = np.empty(4, np.uint32)
+    assert lib.kiss_hip_suffix_sort_dna_u32(None, 3, 256, 0, SA.ctypes.data, 0) == _lib.KISS_HIP_E_INVALID
+    assert lib.kiss_hip_suffix_sort_dna_u32(S.ctypes.data, 3, 256, 0, None, 0) == _lib.KISS_HIP_E_INVALID
+    assert lib.kiss_hip_suffix_sort_dna_u32(S.ctypes.data, 3, 256, 0, SA.ctypes.data, 99) == -2   # no such device
+    c = ctypes.c_void_p()
+    assert lib.kiss_hip_ctx_create(ctypes.byref(c), 0, (1 << 32)) == _lib.KISS_HIP_E_INVALID      # n must fit 32 bits
+    # and the context is still usable after the errors
+    sa = ctx.suffix_sort(S, 256)
+    assert sa[0] == S.size and sorted(sa.tolist()) == list(range(S.size + 1))
