@@ -142,14 +142,19 @@ def main():
     import torch
     import kiss_amd
 
+    # RANK / LOCAL_RANK only mean something under a multi-process launcher (WORLD_SIZE > 1); a stray RANK in the
+    # environment of a single-process run must not turn this process into a silent non-zero rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    else:
+        world, rank, local_rank = 1, 0, 0
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        if world == 1:
+            os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

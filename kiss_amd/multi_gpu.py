@@ -199,7 +199,30 @@ class _Comm:
         return out
 
     def gather_to_root(self, piece, counts, make_empty):
-        """variable-size gather in rank order; returns the concatenation on rank 0, None elsewhere"""
+        """variable-size gather in rank order; returns the concatenation on rank 0, None elsewhere.
+        RCCL: all receives are posted at once (batch_isend_irecv), so the seven xGMI links into rank 0 carry their
+        pieces concurrently instead of one after the other; messages stay below MAX_MSG_BYTES."""
+        if self.stage:  # gloo (tests): through host memory, one source at a time
+            if self.rank == 0:
+                total = int(sum(counts))
+                out = make_empty(total, piece.dtype)
+                off = 0
+                for src in range(self.world):
+                    c = int(counts[src])
+                    if src == 0:
+                        out[off:off + c] = piece
+                    elif c:
+                        buf = self.torch.empty(c, dtype=piece.dtype)
+                        self.dist.recv(buf, src, group=self.group)
+                        out[off:off + c] = buf.to(out.device)
+                    off += c
+                return out
+            if piece.numel():
+                self.dist.send(self._h(piece).contiguous(), 0, group=self.group)
+            return None
+        step = max(1, self.MAX_MSG_BYTES // piece.element_size())
+        ops = []
+        out = None
         if self.rank == 0:
             total = int(sum(counts))
             out = make_empty(total, piece.dtype)
@@ -208,25 +231,18 @@ class _Comm:
                 c = int(counts[src])
                 if src == 0:
                     out[off:off + c] = piece
-                elif c:
-                    if self.stage:
-                        buf = self.torch.empty(c, dtype=piece.dtype)
-                        self.dist.recv(buf, src, group=self.group)
-                        out[off:off + c] = buf.to(out.device)
-                    else:
-                        step = max(1, self.MAX_MSG_BYTES // piece.element_size())
-                        for a in range(0, c, step):
-                            self.dist.recv(out[off + a:off + min(c, a + step)], src, group=self.group)
+                else:
+                    for a in range(0, c, step):
+                        ops.append(self.dist.P2POp(self.dist.irecv, out[off + a:off + min(c, a + step)], src, self.group))
                 off += c
-            return out
-        if piece.numel():
-            if self.stage:
-                self.dist.send(self._h(piece).contiguous(), 0, group=self.group)
-            else:
-                step = max(1, self.MAX_MSG_BYTES // piece.element_size())
-                for a in range(0, int(piece.numel()), step):
-                    self.dist.send(piece[a:a + step].contiguous(), 0, group=self.group)
-        return None
+        else:
+            piece = piece.contiguous()
+            for a in range(0, int(piece.numel()), step):
+                ops.append(self.dist.P2POp(self.dist.isend, piece[a:a + step], 0, self.group))
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
+        return out
 
     def barrier(self):
         self.dist.barrier(group=self.group)
