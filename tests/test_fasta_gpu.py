@@ -113,3 +113,19 @@ def test_missing_file_is_an_error(ctx):
     import kiss_amd
     with pytest.raises(kiss_amd.KissHipError):
         ctx.load_text_file("/nonexistent/file.fa")
+
+
+def test_random_byte_soup(ctx, oracle, tmp_path):
+    # 300 random files over an alphabet rich in '>' and line ends: header / sequence alternation inside runs of
+    # '>' lines, empty lines, CR, files without a final newline -- against the literal restatement of the reader
+    rng = np.random.default_rng(4242)
+    alphabet = np.frombuffer(b"ACGTNacgt>>>\n\n\n\r xy", dtype=np.uint8)
+    for case in range(300):
+        n = int(rng.integers(0, 3000)) if case % 3 else int(rng.integers(0, 12))
+        raw = alphabet[rng.integers(0, alphabet.size, n)].tobytes()
+        if case % 2:
+            raw = b">" + raw
+        try:
+            roundtrip(ctx, oracle, tmp_path, raw, "soup.fa")
+        except AssertionError as e:
+            raise AssertionError("case %d (%r...): %s" % (case, raw[:80], e))

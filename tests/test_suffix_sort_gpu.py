@@ -235,3 +235,50 @@ def test_error_codes(ctx):
     # and the context is still usable after the errors
     sa = ctx.suffix_sort(S, 256)
     assert sa[0] == S.size and sorted(sa.tolist()) == list(range(S.size + 1))
+
+
+def _random_text(rng, n):
+    """small adversarial texts: mixtures of i.i.d. stretches, runs, tandem repeats and copies of earlier pieces"""
+    out = []
+    total = 0
+    while total < n:
+        kind = int(rng.integers(0, 5))
+        ln = int(rng.integers(1, max(2, n // 3 + 1)))
+        if kind == 0:
+            piece = rng.integers(0, 4, ln, dtype=np.uint8)
+        elif kind == 1:
+            piece = np.full(ln, rng.integers(0, 4), dtype=np.uint8)
+        elif kind == 2:
+            unit = rng.integers(0, 4, int(rng.integers(1, 9)), dtype=np.uint8)
+            piece = np.tile(unit, ln // unit.size + 1)[:ln]
+        elif kind == 3 and total > 0:
+            src = np.concatenate(out)
+            a = int(rng.integers(0, src.size))
+            piece = src[a:a + ln].copy()
+            if piece.size == 0:
+                continue
+        else:
+            piece = rng.integers(0, 2, ln, dtype=np.uint8) * int(rng.integers(1, 4))  # two-letter text
+        out.append(piece)
+        total += piece.size
+    return np.concatenate(out)[:n].astype(np.uint8)
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_randomised_small_texts(ctx, oracle, block):
+    # 8 x 40 random (text, k, algorithm) cases per run: stage outputs and SA against the oracle, sizes 0 .. 5000,
+    # k around the stride boundaries of the comparator (125, 250, 375) and unbounded, both exact-order paths
+    import kiss_amd
+    rng = np.random.default_rng(9000 + block)
+    ks = [1, 2, 31, 32, 33, 124, 125, 126, 249, 250, 251, 256, 374, 375, 376, 1000, kiss_amd.K_UNBOUNDED]
+    for case in range(40):
+        n = int(rng.integers(0, 5001)) if case % 4 else int(rng.integers(0, 70))
+        S = _random_text(rng, n) if n else np.zeros(0, np.uint8)
+        k = ks[int(rng.integers(0, len(ks)))]
+        try:
+            check_parity(ctx, oracle, S, k)
+            if k == kiss_amd.K_UNBOUNDED:
+                sa1 = ctx.suffix_sort(S, k, algo=1)
+                assert np.array_equal(sa1, oracle.suffix_sort(S, k)), "PREFIX_DOUBLING"
+        except AssertionError as e:
+            raise AssertionError("block %d case %d: n=%d k=%d text=%s...: %s" % (block, case, n, k, S[:60].tolist(), e))
