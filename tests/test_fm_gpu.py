@@ -60,3 +60,29 @@ def test_config3_shape(oracle):
     assert a["total_hits"] == b["total_hits"] and a["checksum"] == b["checksum"]
     assert np.array_equal(a["beg"], b["beg"]) and np.array_equal(a["end"], b["end"])
     f.close()
+
+
+@pytest.mark.parametrize("L", [2, 7, 12, 40])
+def test_heavy_patterns_keep_the_fifo_order(oracle, L):
+    # patterns with thousands of occurrences (tandem repeats, homopolymers) are located by a workgroup
+    # (fm.hip k_fm_locate_heavy): offsets must come out in the reference's breadth-first order, and the text
+    # starts inside a repeat so that the primary row sits in a heavy range
+    import kiss_amd.fm_index as fm
+    rng = np.random.default_rng(77)
+    S = gen.iid(300_000, 5)
+    S[:40_000] = np.tile(np.array([0, 1, 2], np.uint8), 13_334)[:40_000]
+    S[100_000:160_000] = 3
+    S[200_000:230_000] = np.tile(rng.integers(0, 4, 11, dtype=np.uint8), 2728)[:30_000]
+    f = fm.FMIndex().build(S)
+    ref = oracle.fm_build(S, oracle.suffix_sort(S, 32))
+    pos = np.concatenate([rng.integers(0, 40_000 - L, 300), rng.integers(100_000, 160_000 - L, 300),
+                          rng.integers(200_000, 230_000 - L, 300), rng.integers(0, S.size - L, 300), np.arange(8)])
+    pats = np.stack([S[p:p + L] for p in pos]).astype(np.uint8)
+    a = f.query_batch(pats)
+    b = ref.query_batch(pats)
+    assert np.array_equal(a["beg"], b["beg"]) and np.array_equal(a["end"], b["end"])
+    assert int((b["end"].astype(np.int64) - b["beg"]).max()) > 5000
+    assert a["total_hits"] == b["total_hits"] and a["checksum"] == b["checksum"]
+    assert np.array_equal(a["offsets_index"], b["offsets_index"])
+    assert np.array_equal(a["offsets"], b["offsets"])
+    f.close()
