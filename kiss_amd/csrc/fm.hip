@@ -14,6 +14,8 @@
 //                have been collected (get_offsets :453-501).
 // One lane owns one pattern: 2L dependent LF steps of three small loads each (16 B + 4 B + 4 B) --
 // a latency-bound gather workload, so the grid keeps every CU's 2048 lanes busy rather than tiling.
+// Locate: patterns with more than FM_HEAVY occurrences (tandem repeats reach 10^6) get a workgroup of their own,
+// the rest stay one lane per pattern; both produce the reference's output order.
 #include "kiss_internal.hpp"
 
 namespace {
@@ -319,11 +321,6 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_gather_offsets_flat(const uin
         else hi = mid;
     }
     offsets[o] = scratch[cap_index[lo] + (o - off_index[lo])];
-}
-
-__global__ void k_set_last_u64(uint64_t *arr, uint64_t idx, const uint64_t *ex, const uint64_t *vals)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) arr[idx] = ex[idx - 1] + vals[idx - 1];
 }
 
 // ---- construction --------------------------------------------------------------------------------------

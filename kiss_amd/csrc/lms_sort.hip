@@ -12,8 +12,11 @@
 //             - a segment of <= SMALL_SEG suffixes is FINISHED on the spot: one lane per suffix ranks it
 //               against the others of its segment, first on the fetched key and, for pairs that tie on it,
 //               by walking both suffixes to the full depth D (then position).  All of them retire.
-//             - larger segments are compacted, radix sorted on (segment id, key), split where neighbours
-//               differ, and go round again (their pieces are usually small and finish next round).
+//             - larger segments are compacted and sorted on (segment id, key): from the second refinement round on
+//               by a stable three-way split around the key of the segment's middle item (what is left then is
+//               mostly long tandem arrays, whose members carry one key per round) followed by a radix sort of the
+//               < and > groups only; in the first round by the radix sort directly.  Then they are split where
+//               neighbours differ and go round again.
 // Every step is stable and the initial order is ascending text position, which yields the reference's
 // position tie-break (kiss1_core.hpp:131-133) once the depth D is exhausted.
 #include "kiss_internal.hpp"
@@ -284,51 +287,6 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__
 }
 
 
-
-// flags[i] = (survivor << 32) | surviving_head ; keys are compared on bits [cmp_shift, 64)
-template <bool HAS_SEG>
-__global__ __launch_bounds__(LS_THREADS) void k_flag(const uint64_t *__restrict__ key,
-                                                    const uint32_t *__restrict__ seg, uint64_t count, int cmp_shift,
-                                                    int last_round, uint64_t *__restrict__ flags)
-{
-    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= count) return;
-    uint64_t k = key[i] >> cmp_shift;
-    uint32_t s = HAS_SEG ? seg[i] : 0u;
-    bool head = (i == 0) || (key[i - 1] >> cmp_shift) != k || (HAS_SEG && seg[i - 1] != s);
-    bool nhead = (i + 1 == count) || (key[i + 1] >> cmp_shift) != k || (HAS_SEG && seg[i + 1] != s);
-    bool single = head && nhead;
-    bool surv = !single && !last_round;
-    flags[i] = ((uint64_t)(surv ? 1u : 0u) << 32) | (uint64_t)((surv && head) ? 1u : 0u);
-}
-
-// retire singletons (and everything in the last round) into out[slot]; compact survivors and record
-// where every surviving segment starts
-template <bool HAS_SLOT>
-__global__ __launch_bounds__(LS_THREADS) void k_compact(const uint32_t *__restrict__ pos,
-                                                       const uint32_t *__restrict__ slot, uint64_t count,
-                                                       const uint64_t *__restrict__ flags_in,
-                                                       const uint64_t *__restrict__ ex, uint32_t *__restrict__ npos,
-                                                       uint32_t *__restrict__ nslot, uint32_t *__restrict__ nseg,
-                                                       uint32_t *__restrict__ nsegstart, uint32_t *__restrict__ out)
-{
-    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= count) return;
-    uint64_t f = flags_in[i];
-    uint64_t e = ex[i];
-    uint32_t sl = HAS_SLOT ? slot[i] : (uint32_t)i;
-    uint32_t p = pos[i];
-    if (f >> 32) {
-        uint32_t ni = (uint32_t)(e >> 32);
-        uint32_t sid = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
-        npos[ni] = p;
-        nslot[ni] = sl;
-        nseg[ni] = sid;
-        if (f & 1ull) nsegstart[sid] = ni;
-    } else {
-        out[sl] = p;
-    }
-}
 
 // ---- fused flag + compaction over 2048-item tiles (no per-item flag / scan arrays) ------------------------
 // pass 1: per-tile (survivors << 32 | surviving heads); pass 2 (after an exclusive scan over tiles): the same
