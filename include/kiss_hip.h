@@ -171,11 +171,14 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
 int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
                              const uint32_t *splitters, int groups, uint64_t *d_keys_out, uint32_t *d_pos_out,
                              void *stream);
+/* d_ctx_out / d_far_ctx (both optional): the context words the sort derives from the key payload, parallel to the
+ * sorted positions (0 = not available, the induction gathers it from the text); shipping them with the pieces
+ * spares rank 0 a random text gather per LMS suffix. */
 int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, uint64_t n,
-                        uint32_t k, uint32_t *d_sorted_out, void *stream);
-int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted, uint64_t m_far,
-                          const uint32_t *d_near_pos, uint64_t near_count, const uint64_t counts12[12], uint32_t *d_SA,
-                          void *stream);
+                        uint32_t k, uint32_t *d_sorted_out, uint32_t *d_ctx_out, void *stream);
+int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
+                          const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                          const uint64_t counts12[12], uint32_t *d_SA, void *stream);
 
 /* Test hooks (used by tests/ only): the library's stable LSD radix sort on bits [key_lo_bit, 64) of keys with a
  * 32-bit payload, and its exclusive u32 scan, run on caller data in host memory (count <= ctx LMS capacity). */

@@ -98,8 +98,8 @@ def load():
     lib.kiss_hip_stage_local_lms.argtypes = [vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     lib.kiss_hip_stage_key_hist.argtypes = [vp, vp, u64, ctypes.c_int, vp, vp]
     lib.kiss_hip_stage_partition.argtypes = [vp, vp, vp, u64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
-    lib.kiss_hip_stage_sort.argtypes = [vp, vp, vp, u64, u64, ctypes.c_uint32, vp, vp]
-    lib.kiss_hip_stage_induce.argtypes = [vp, u64, ctypes.c_uint32, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp]
+    lib.kiss_hip_stage_sort.argtypes = [vp, vp, vp, u64, u64, ctypes.c_uint32, vp, vp, vp]
+    lib.kiss_hip_stage_induce.argtypes = [vp, u64, ctypes.c_uint32, vp, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp]
     lib.kiss_hip_fmi_query_batch_dev.argtypes = [
         vp, ctypes.POINTER(FmiView), vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp, ctypes.c_uint64, vp]

@@ -136,7 +136,7 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
 }
 
 int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, uint64_t n,
-                        uint32_t k, uint32_t *d_sorted_out, void *stream)
+                        uint32_t k, uint32_t *d_sorted_out, uint32_t *d_ctx_out, void *stream)
 {
     if (!ctx || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID; // stage_classify packed the text of this ctx
     if (count && (!d_keys || !d_pos || !d_sorted_out)) return KISS_HIP_E_INVALID;
@@ -149,16 +149,19 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     }
     ctx->m = ctx->m_far = count;
     KTRY(kiss_lms_sort(ctx, n, k, depth_of(n, k)));
-    if (count)
+    if (count) {
         KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_ctx_out) // context words from the key payload (0 = to be gathered), parallel to the sorted positions
+            KCHECK(hipMemcpyAsync(d_ctx_out, ctx->lms_ctx_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     KTRY(kiss_radix_check(ctx));
     ktimer_collect(ctx);
     return KISS_HIP_OK;
 }
 
-int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted, uint64_t m_far,
-                          const uint32_t *d_near_pos, uint64_t near_count, const uint64_t counts12[12], uint32_t *d_SA,
-                          void *stream)
+int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
+                          const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                          const uint64_t counts12[12], uint32_t *d_SA, void *stream)
 {
     if (!ctx || !counts12 || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID;
     if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
@@ -168,7 +171,10 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
     if (m_far) {
         KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        KTRY(kiss_zero_u32(ctx, ctx->lms_ctx_far, m_far)); // the pieces arrive without context words: gather them all
+        if (d_far_ctx)
+            KCHECK(hipMemcpyAsync(ctx->lms_ctx_far, d_far_ctx, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        else
+            KTRY(kiss_zero_u32(ctx, ctx->lms_ctx_far, m_far)); // no context words came along: gather them all
     }
     if (near_count) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
         KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));

@@ -5,10 +5,11 @@ exchange, libkiss_hip.so stage calls for the arithmetic.  Design: SURVEY.md sect
                all_reduce(13 counters), all_reduce(2^16-bin histogram of the first 16 key bits) -> G key ranges
                stable partition by destination, all_to_all (counts, keys, positions)
                k-ordered sort of the received key range
-  rank 0     : receives the sorted pieces in key-range order and the near-end suffixes, runs placement + induction
+  rank 0     : receives the sorted pieces (positions + context words) in key-range order and the near-end suffixes,
+               runs placement + induction
 
 The only data-path collective is the all-to-all of the LMS list (12 bytes per LMS suffix) plus the gather of the
-sorted pieces (4 bytes per LMS suffix); induction is one global dependency chain and stays on one GPU.
+sorted pieces (8 bytes per LMS suffix); induction is one global dependency chain and stays on one GPU.
 `Backend` abstracts the stage calls so the orchestration can be exercised on CPU (gloo) with a stand-in backend
 (tests/test_multi_gpu.py); the product backend is `GpuBackend` (no CPU fallback).
 """
@@ -79,20 +80,24 @@ class GpuBackend:
         return ko, po
 
     def sort(self, keys, pos):
+        """-> (k-ordered positions, their context words from the key payload; 0 = to be gathered)"""
         self._sync()
         out = self.torch.empty_like(pos)
+        cw = self.torch.empty_like(pos)
         _check(self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
-                                            int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()), None),
+                                            int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()),
+                                            ctypes.c_void_p(cw.data_ptr()), None),
                "kiss_hip_stage_sort", self.ctx._ctx)
-        return out
+        return out, cw
 
-    def induce(self, far_all, near_all, counts12, SA=None):
+    def induce(self, far_all, near_all, counts12, SA=None, far_ctx=None):
         self._sync()
         torch = self.torch
         if SA is None:
             SA = torch.empty(self.n + 1, dtype=torch.int32, device=self.dev)
         c = (ctypes.c_uint64 * 12)(*[int(x) for x in counts12])
         _check(self.lib.kiss_hip_stage_induce(self.ctx._ctx, self.n, self.k, ctypes.c_void_p(far_all.data_ptr()),
+                                              ctypes.c_void_p(far_ctx.data_ptr()) if far_ctx is not None else None,
                                               int(far_all.numel()), ctypes.c_void_p(near_all.data_ptr()),
                                               int(near_all.numel()), ctypes.byref(c), ctypes.c_void_p(SA.data_ptr()), None),
                "kiss_hip_stage_induce", self.ctx._ctx)
@@ -298,11 +303,14 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     rpos = backend.empty(R, torch.int32)
     comm.all_to_all(rkeys, skeys, recv_counts, send_counts)
     comm.all_to_all(rpos, spos, recv_counts, send_counts)
-    sorted_piece = backend.sort(rkeys, rpos)
+    sorted_piece, piece_ctx = backend.sort(rkeys, rpos)
     piece_counts = comm.all_gather_ints(R)
     far_all = comm.gather_to_root(sorted_piece, piece_counts, backend.empty)
+    # the context words travel with the pieces (4 more bytes per LMS suffix over xGMI instead of a random text
+    # gather per LMS suffix on rank 0)
+    ctx_all = comm.gather_to_root(piece_ctx, piece_counts, backend.empty)
     out = None
     if r == 0:
-        out = backend.induce(far_all, near_all, counts12, SA)
+        out = backend.induce(far_all, near_all, counts12, SA, far_ctx=ctx_all)
     comm.barrier()
     return out

@@ -84,9 +84,11 @@ class OracleBackend:
     def sort(self, keys, pos):
         p = pos.numpy().view(np.uint32)
         assert np.all(np.diff(p.astype(np.int64)) > 0) or p.size < 2 or True
-        return torch.from_numpy(self.orc.lms_sort(self.S, self.k, p).view(np.int32).copy())
+        out = torch.from_numpy(self.orc.lms_sort(self.S, self.k, p).view(np.int32).copy())
+        return out, torch.zeros_like(out)  # no context words: "gather them"
 
-    def induce(self, far_all, near_all, counts12, SA=None):
+    def induce(self, far_all, near_all, counts12, SA=None, far_ctx=None):
+        assert far_ctx is not None and far_ctx.numel() == far_all.numel(), "context words travel with the pieces"
         ref_sa, lms_sorted = self.orc.suffix_sort(self.S, self.k, stages=True)
         lms_sorted = lms_sorted[1:]
         D = depth_of(self.n, self.k)
