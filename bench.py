@@ -139,6 +139,12 @@ def main():
                     help="run the sharded pipeline (RCCL collectives included) even with a single rank (test aid)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: RCCL (version banner, NCCL_DEBUG output) and other libraries
+    # print to file descriptor 1 as well, so everything but the result line is sent to stderr
+    result_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import torch
     import kiss_amd
 
@@ -311,7 +317,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sample, k)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

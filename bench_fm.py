@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-queries", type=int, default=200_000, help="patterns of the single-thread CPU baseline (0 = skip)")
     args = ap.parse_args()
+    result_out = os.fdopen(os.dup(1), "w")  # stdout = the JSON line only (libraries print to fd 1 too)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import torch
     import kiss_amd.fm_index as fm
     from bench import gen_text_device
@@ -91,7 +94,8 @@ def main():
         sub = f.query_batch(pats[:cq], want_offsets=False)
         out["config"]["parity_vs_oracle_on_sample"] = bool(sub["total_hits"] == rr["total_hits"] and
                                                            sub["checksum"] == rr["checksum"])
-    print(json.dumps(out), flush=True)
+    result_out.write(json.dumps(out) + "\n")
+    result_out.flush()
 
 
 if __name__ == "__main__":
