@@ -121,21 +121,41 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         for (int c = 0; c < 4; c++) wtot[wave][c] = run[c];
     }
     __syncthreads();
-    uint32_t off[4];
+    // stage the tile class by class in LDS, then write every class as one contiguous run (full 256-byte stores
+    // instead of 64-byte pieces per wave and iteration)
+    __shared__ uint32_t stP[IN_TILE], stC[IN_TILE];
+    uint32_t coff[5]; // start of class c inside the staged tile
+    uint32_t woff[4]; // this wave's start inside class c
+    coff[0] = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        uint32_t o = ex[(uint64_t)c * tiles + blockIdx.x] - ex[(uint64_t)c * tiles];
-        for (int w = 0; w < wave; w++) o += wtot[w][c];
-        off[c] = o;
+        uint32_t t = 0, w0 = 0;
+        for (int w = 0; w < IN_WAVES; w++) {
+            if (w < wave) w0 += wtot[w][c];
+            t += wtot[w][c];
+        }
+        woff[c] = w0;
+        coff[c + 1] = coff[c] + t;
     }
 #pragma unroll
     for (int j = 0; j < IN_ITEMS; j++) {
-        uint32_t cls = rr[j] >> 28;
+        const uint32_t cls = rr[j] >> 28;
         if (cls < 4u) {
-            int64_t d = dst.p[cls] + (int64_t)dir * (int64_t)(off[cls] + (rr[j] & 0x0FFFFFFFu));
-            SA[d] = vv[j] - 1u;
-            CTX[d] = cc[j] >> 2;
+            const uint32_t li = coff[cls] + woff[cls] + (rr[j] & 0x0FFFFFFFu);
+            stP[li] = vv[j] - 1u;
+            stC[li] = cc[j] >> 2;
         }
+    }
+    __syncthreads();
+    const uint32_t total = coff[4];
+    for (uint32_t li = threadIdx.x; li < total; li += IN_THREADS) {
+        const uint32_t cls = li < coff[1] ? 0u : (li < coff[2] ? 1u : (li < coff[3] ? 2u : 3u));
+        const uint32_t toff = ex[(uint64_t)cls * tiles + blockIdx.x] - ex[(uint64_t)cls * tiles];
+        const uint32_t cstart = cls == 0 ? coff[0] : (cls == 1 ? coff[1] : (cls == 2 ? coff[2] : coff[3]));
+        const int64_t dp = cls == 0 ? dst.p[0] : (cls == 1 ? dst.p[1] : (cls == 2 ? dst.p[2] : dst.p[3]));
+        const int64_t d = dp + (int64_t)dir * (int64_t)(toff + (li - cstart));
+        SA[d] = stP[li];
+        CTX[d] = stC[li];
     }
 }
 
