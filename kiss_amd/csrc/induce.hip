@@ -53,9 +53,21 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
     return ((emitmask >> pc) & 1u) ? pc : 4u;
 }
 
-// (A single-pass form with decoupled look-back -- the one the radix scatter uses -- was measured at chm13 size:
-//  39.5 ms with 2048-item tiles, 35.0 ms with 8192-item tiles, against 31.6 ms for count + scan + scatter below:
-//  four counters per tile are too little work to hide the look-back latency.)
+// the count pass only needs the class: the position is read only when the context word has run empty
+__device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
+                                                    int64_t phys, uint32_t emitmask)
+{
+    uint32_t c = srcC[phys];
+    if (c == KISS_EMPTY_CTX) {
+        const uint32_t v = srcP[phys];
+        if (v == 0) return 4u;
+        c = kiss_load_ctx(pk, v);
+        srcC[phys] = c;
+    }
+    const uint32_t pc = c & 3u;
+    return ((emitmask >> pc) & 1u) ? pc : 4u;
+}
+
 // ---- pass 1: per-tile class counts ---------------------------------------------------
 __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                             uint32_t *srcC, int64_t beg, uint64_t N, int dir,
@@ -67,14 +79,19 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     __syncthreads();
     const int wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)wave * IN_WAVE_TILE + lane_id();
-    uint32_t run[4] = {0, 0, 0, 0};
+    uint32_t run[4] = {0, 0, 0, 0}; // per lane, summed over the wave once at the end
 #pragma unroll
     for (int j = 0; j < IN_ITEMS; j++) {
         uint64_t i = base + (uint64_t)j * 64;
-        uint32_t cls = 4u, v, cw;
-        if (i < N) cls = item_class(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &cw);
+        uint32_t cls = 4u;
+        if (i < N) cls = item_class_only(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask);
 #pragma unroll
-        for (int c = 0; c < 4; c++) run[c] += (uint32_t)__popcll(__ballot(cls == (uint32_t)c));
+        for (int c = 0; c < 4; c++) run[c] += cls == (uint32_t)c ? 1u : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) run[c] += __shfl_xor(run[c], d, 64);
     }
     if (lane_id() == 0) {
 #pragma unroll
