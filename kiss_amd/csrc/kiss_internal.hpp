@@ -134,6 +134,7 @@ struct RadixBufs {
     uint64_t *key[2];
     uint32_t *seg[2]; // may be null when seg_bits == 0
     uint32_t *pos[2];
+    const uint32_t *first_pos = nullptr; // optional: the first pass reads its positions from here instead of pos[0]
 };
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
 int kiss_radix_check(kiss_hip_ctx *ctx); // synchronises; KISS_HIP_E_INTERNAL if a look-back wait ran out

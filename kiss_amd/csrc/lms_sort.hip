@@ -542,8 +542,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 
     // ------------------------------ round 0 ------------------------------------------------
     uint64_t count = m_far;
-    KCHECK(hipMemcpyAsync(ctx->posA, ctx->lms_pos, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     RadixBufs rb;
+    rb.first_pos = ctx->lms_pos; // the ascending list stays intact: the first pass reads it, nothing writes it
     rb.key[0] = ctx->keyA;
     rb.key[1] = ctx->keyB;
     rb.pos[0] = ctx->posA;

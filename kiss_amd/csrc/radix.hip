@@ -473,7 +473,7 @@ int radix_offsets(kiss_hip_ctx *ctx, uint64_t tiles)
 }
 
 template <int SRC, bool HAS_SEG>
-int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift)
+int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift, const uint32_t *pos_in)
 {
     const uint64_t tiles = div_up(count, RX_TILE);
     const int dst = src ^ 1;
@@ -487,7 +487,7 @@ int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shi
     {
         KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
         hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG, false>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
-                           b.key[src], b.seg[src], b.pos[src], b.key[dst], b.seg[dst], b.pos[dst], count, shift,
+                           b.key[src], b.seg[src], pos_in, b.key[dst], b.seg[dst], b.pos[dst], count, shift,
                            ctx->tile_hist, tiles, nullptr, nullptr, 0u, 0ull);
         KCHECK(hipGetLastError());
     }
@@ -496,14 +496,14 @@ int radix_pass(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shi
 
 // one-sweep pass p (digit bases already in rx_ghist[p])
 template <int SRC, bool HAS_SEG>
-int radix_pass_one(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift, int p)
+int radix_pass_one(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int shift, int p, const uint32_t *pos_in)
 {
     const uint64_t tiles = div_up(count, RX_TILE);
     const int dst = src ^ 1;
     KTimer t(ctx, KISS_HIP_K_RADIX_SCATTER, count);
     ctx->rx_epoch++;
     hipLaunchKernelGGL((k_radix_scatter<SRC, HAS_SEG, true>), dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream,
-                       b.key[src], b.seg[src], b.pos[src], b.key[dst], b.seg[dst], b.pos[dst], count, shift,
+                       b.key[src], b.seg[src], pos_in, b.key[dst], b.seg[dst], b.pos[dst], count, shift,
                        ctx->rx_ghist + 256 * p, tiles, ctx->rx_desc, ctx->rx_ctl, ctx->rx_ticket_base, ctx->rx_epoch);
     KCHECK(hipGetLastError());
     ctx->rx_ticket_base += (uint32_t)tiles;
@@ -554,21 +554,25 @@ int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_
         }
         int p = 0;
         for (int shift = shift0; shift < 64; shift += 8, p++) {
+            const uint32_t *pin = (p == 0 && b.first_pos) ? b.first_pos : b.pos[cur];
             if (one) {
-                if (has_seg) KTRY((radix_pass_one<0, true>(ctx, b, cur, count, shift, p)));
-                else KTRY((radix_pass_one<0, false>(ctx, b, cur, count, shift, p)));
+                if (has_seg) KTRY((radix_pass_one<0, true>(ctx, b, cur, count, shift, p, pin)));
+                else KTRY((radix_pass_one<0, false>(ctx, b, cur, count, shift, p, pin)));
             } else {
-                if (has_seg) KTRY((radix_pass<0, true>(ctx, b, cur, count, shift)));
-                else KTRY((radix_pass<0, false>(ctx, b, cur, count, shift)));
+                if (has_seg) KTRY((radix_pass<0, true>(ctx, b, cur, count, shift, pin)));
+                else KTRY((radix_pass<0, false>(ctx, b, cur, count, shift, pin)));
             }
             cur ^= 1;
         }
         for (int shift = 0; shift < seg_bits; shift += 8, p++) {
-            if (one) KTRY((radix_pass_one<1, true>(ctx, b, cur, count, shift, p)));
-            else KTRY((radix_pass<1, true>(ctx, b, cur, count, shift)));
+            const uint32_t *pin = (p == 0 && b.first_pos) ? b.first_pos : b.pos[cur];
+            if (one) KTRY((radix_pass_one<1, true>(ctx, b, cur, count, shift, p, pin)));
+            else KTRY((radix_pass<1, true>(ctx, b, cur, count, shift, pin)));
             cur ^= 1;
         }
     }
+    if (count <= 1 && b.first_pos && count == 1) // nothing moved: the caller still expects the positions in pos[0]
+        KCHECK(hipMemcpyAsync(b.pos[0], b.first_pos, sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
     *result_idx = cur;
     return KISS_HIP_OK;
 }
