@@ -282,3 +282,28 @@ def test_randomised_small_texts(ctx, oracle, block):
                 assert np.array_equal(sa1, oracle.suffix_sort(S, k)), "PREFIX_DOUBLING"
         except AssertionError as e:
             raise AssertionError("block %d case %d: n=%d k=%d text=%s...: %s" % (block, case, n, k, S[:60].tolist(), e))
+
+
+def test_fallback_paths_in_a_fresh_process():
+    # two switches are read once per process / per workspace: KISS_HIP_NO_ONESWEEP (radix passes with per-tile
+    # histograms instead of look-back) and KISS_HIP_TCAP0 (tiny tied-segment arrays, so every growth path runs).
+    # One child process sorts a handful of texts with both set and compares with the oracle.
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import numpy as np, kiss_amd
+from tests import gen, oracle_binding
+orc = oracle_binding.load()
+ctx = kiss_amd.Context(max_n=400_000)
+texts = [gen.genome_like(300_000, 3), gen.periodic(200_000, 7, 1, 40), np.zeros(100_000, np.uint8),
+         np.tile(np.array([0, 1], np.uint8), 150_000), gen.iid(250_000, 4)]
+for S in texts:
+    for k, algo in ((256, 0), (32, 0), (kiss_amd.K_UNBOUNDED, 1)):
+        assert np.array_equal(ctx.suffix_sort(S, k, algo=algo), orc.suffix_sort(S, k)), (S[:8], k, algo)
+print("variants ok")
+"""
+    env = dict(os.environ, KISS_HIP_NO_ONESWEEP="1", KISS_HIP_TCAP0="1500", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
