@@ -63,8 +63,11 @@ def main():
     kms = f._ctx.stats()["kernels"]["fm_query"]["ms"] - kms0
     qps = Q * args.steps / el
     hits = r["total_hits"]
-    # algorithmic bytes: 48 L per pattern + 64 per hit
-    bytes_per_step = 48.0 * L * Q + 64.0 * hits
+    # algorithmic bytes of THIS formulation: backward search = 2 LF steps of 24 B per pattern character; locate walks
+    # ranges, not hits (<= 85 ranges per pattern), so a hit costs its sampled-SA word in and its offset out (8 B).
+    # SURVEY.md 8(d) prices the reference's walk at 48 L per pattern + 64 B per hit (one LF walk per hit).
+    bytes_per_step = 48.0 * L * Q + 8.0 * hits
+    survey_bytes_per_step = 48.0 * L * Q + 64.0 * hits
     kernel_s = 1e-3 * kms / args.steps
     out = {
         "metric": "FM-index queries/sec (batched get_range + get_offsets, 32-base patterns)",
@@ -77,7 +80,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_fm_range+k_fm_locate", "achieved": bytes_per_step / kernel_s / 1e9,
                      "peak": 8000.0, "unit": "GB/s", "frac": bytes_per_step / kernel_s / 1e9 / 8000.0, "traffic": None,
                      "kernel_ms_per_step": 1e3 * kernel_s,
-                     "note": "index (~85 MB) is Infinity-Cache resident: latency-bound, HBM fraction small by construction"},
+                     "algorithmic_bytes_per_step": bytes_per_step,
+                     "survey_8d_bytes_per_step": survey_bytes_per_step,
+                     "note": "bytes = 48 L per pattern + 8 per hit (range-wise locate); a dm-sized index (~85 MB) is "
+                             "Infinity-Cache resident, so this is a latency-bound gather workload and the HBM fraction "
+                             "says little"},
     }
     if args.cpu_queries > 0:
         from tests import oracle_binding
