@@ -77,16 +77,39 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     __shared__ uint32_t tc[4];
     if (threadIdx.x < 4) tc[threadIdx.x] = 0;
     __syncthreads();
-    const int wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)wave * IN_WAVE_TILE + lane_id();
+    // counting does not care about order: a lane takes IN_ITEMS consecutive items (two 16-byte loads, 4-byte aligned)
+    struct __attribute__((packed, aligned(4))) U4 {
+        uint32_t v[4];
+    };
     uint32_t run[4] = {0, 0, 0, 0}; // per lane, summed over the wave once at the end
+    const uint64_t i0 = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
+    if (i0 + IN_ITEMS <= N) {
+        const int64_t p0 = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1); // lowest address of my items
+        uint32_t cw[IN_ITEMS];
 #pragma unroll
-    for (int j = 0; j < IN_ITEMS; j++) {
-        uint64_t i = base + (uint64_t)j * 64;
-        uint32_t cls = 4u;
-        if (i < N) cls = item_class_only(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask);
+        for (int q = 0; q < IN_ITEMS / 4; q++) {
+            const U4 t = *reinterpret_cast<const U4 *>(srcC + p0 + 4 * q);
 #pragma unroll
-        for (int c = 0; c < 4; c++) run[c] += cls == (uint32_t)c ? 1u : 0u;
+            for (int e = 0; e < 4; e++) cw[4 * q + e] = t.v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < IN_ITEMS; e++) {
+            uint32_t c = cw[e];
+            uint32_t cls;
+            if (c == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0 + e, emitmask); // refresh path
+            else {
+                const uint32_t pc = c & 3u;
+                cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) run[k] += cls == (uint32_t)k ? 1u : 0u;
+        }
+    } else {
+        for (uint64_t i = i0; i < N && i < i0 + IN_ITEMS; i++) {
+            const uint32_t cls = item_class_only(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask);
+#pragma unroll
+            for (int k = 0; k < 4; k++) run[k] += cls == (uint32_t)k ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
