@@ -28,7 +28,6 @@ namespace {
 constexpr int IN_THREADS = 256;
 constexpr int IN_ITEMS = 8;
 constexpr int IN_WAVES = IN_THREADS / 64;
-constexpr int IN_WAVE_TILE = IN_ITEMS * 64;      // 512
 constexpr int IN_TILE = IN_THREADS * IN_ITEMS;   // 2048
 constexpr int SM_THREADS = 1024;
 constexpr uint64_t SMALL_MAX = 8192;             // rounds up to this size run in the single-workgroup kernel
@@ -137,24 +136,81 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
 {
     __shared__ uint32_t wtot[IN_WAVES][4];
     const int wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)wave * IN_WAVE_TILE + lane_id();
-    uint32_t run[4] = {0, 0, 0, 0};
+    // A thread owns IN_ITEMS consecutive items (item order = thread order, then order inside the thread), read with
+    // 16-byte loads; its rank inside a class = items of that class in lower lanes (wave prefix of the per-lane
+    // counts) + earlier ones of its own.
+    struct __attribute__((packed, aligned(4))) U4 {
+        uint32_t v[4];
+    };
+    const uint64_t i0 = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
     uint32_t vv[IN_ITEMS], cc[IN_ITEMS], rr[IN_ITEMS]; // rr = (class << 28) | rank in wave
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    if (i0 + IN_ITEMS <= N) {
+        const int64_t p0 = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1); // lowest address of my items
+        uint32_t bp[IN_ITEMS], bc[IN_ITEMS];
 #pragma unroll
-    for (int j = 0; j < IN_ITEMS; j++) {
-        uint64_t i = base + (uint64_t)j * 64;
-        uint32_t cls = 4u, v = 0, cw = 0;
-        if (i < N) cls = item_class(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &cw);
-        uint32_t myrank = 0;
+        for (int q = 0; q < IN_ITEMS / 4; q++) {
+            const U4 tp = *reinterpret_cast<const U4 *>(srcP + p0 + 4 * q);
+            const U4 tcw = *reinterpret_cast<const U4 *>(srcC + p0 + 4 * q);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            uint64_t mk = __ballot(cls == (uint32_t)c);
-            if (cls == (uint32_t)c) myrank = run[c] + (uint32_t)__popcll(mk & lanemask_lt());
-            run[c] += (uint32_t)__popcll(mk);
+            for (int e = 0; e < 4; e++) {
+                bp[4 * q + e] = tp.v[e];
+                bc[4 * q + e] = tcw.v[e];
+            }
         }
-        vv[j] = v;
-        cc[j] = cw;
-        rr[j] = (cls << 28) | myrank;
+#pragma unroll
+        for (int e = 0; e < IN_ITEMS; e++) {
+            const int a = dir > 0 ? e : IN_ITEMS - 1 - e; // place of item e inside the block
+            uint32_t v = bp[a], c = bc[a], cls;
+            if (c == KISS_EMPTY_CTX) cls = item_class(pk, srcP, srcC, p0 + a, emitmask, &v, &c); // refresh path
+            else {
+                const uint32_t pc = c & 3u;
+                cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+            }
+            uint32_t local = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (cls == (uint32_t)k) local = cnt[k];
+                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
+            }
+            vv[e] = v;
+            cc[e] = c;
+            rr[e] = (cls << 28) | local;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < IN_ITEMS; e++) {
+            const uint64_t i = i0 + (uint64_t)e;
+            uint32_t cls = 4u, v = 0, c = 0;
+            if (i < N) cls = item_class(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &c);
+            uint32_t local = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (cls == (uint32_t)k) local = cnt[k];
+                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
+            }
+            vv[e] = v;
+            cc[e] = c;
+            rr[e] = (cls << 28) | local;
+        }
+    }
+    uint32_t run[4]; // wave totals
+    uint32_t lex[4]; // items of class k in lower lanes
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t inc = cnt[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if ((int)lane_id() >= d) inc += o;
+        }
+        lex[k] = inc - cnt[k];
+        run[k] = __shfl(inc, 63, 64);
+    }
+#pragma unroll
+    for (int e = 0; e < IN_ITEMS; e++) {
+        const uint32_t cls = rr[e] >> 28;
+        if (cls < 4u) rr[e] += cls == 0 ? lex[0] : (cls == 1 ? lex[1] : (cls == 2 ? lex[2] : lex[3]));
     }
     if (lane_id() == 0) {
 #pragma unroll
