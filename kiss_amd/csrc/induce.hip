@@ -243,15 +243,38 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         }
     }
     __syncthreads();
+    // write-out: a thread takes four consecutive staged items of one class and stores them with one 16-byte store
+    // per array (4-byte aligned); class boundaries and the tail fall back to single stores
     const uint32_t total = coff[4];
-    for (uint32_t li = threadIdx.x; li < total; li += IN_THREADS) {
-        const uint32_t cls = li < coff[1] ? 0u : (li < coff[2] ? 1u : (li < coff[3] ? 2u : 3u));
-        const uint32_t toff = ex[(uint64_t)cls * tiles + blockIdx.x] - ex[(uint64_t)cls * tiles];
-        const uint32_t cstart = cls == 0 ? coff[0] : (cls == 1 ? coff[1] : (cls == 2 ? coff[2] : coff[3]));
-        const int64_t dp = cls == 0 ? dst.p[0] : (cls == 1 ? dst.p[1] : (cls == 2 ? dst.p[2] : dst.p[3]));
-        const int64_t d = dp + (int64_t)dir * (int64_t)(toff + (li - cstart));
-        SA[d] = stP[li];
-        CTX[d] = stC[li];
+    for (uint32_t l0 = threadIdx.x * 4u; l0 < total; l0 += IN_THREADS * 4u) {
+        const uint32_t cls = l0 < coff[1] ? 0u : (l0 < coff[2] ? 1u : (l0 < coff[3] ? 2u : 3u));
+        const uint32_t cend = cls == 0 ? coff[1] : (cls == 1 ? coff[2] : (cls == 2 ? coff[3] : coff[4]));
+        if (l0 + 4u <= cend) {
+            const uint32_t toff = ex[(uint64_t)cls * tiles + blockIdx.x] - ex[(uint64_t)cls * tiles];
+            const uint32_t cstart = cls == 0 ? coff[0] : (cls == 1 ? coff[1] : (cls == 2 ? coff[2] : coff[3]));
+            const int64_t dp = cls == 0 ? dst.p[0] : (cls == 1 ? dst.p[1] : (cls == 2 ? dst.p[2] : dst.p[3]));
+            const int64_t d0 = dp + (int64_t)dir * (int64_t)(toff + (l0 - cstart)); // place of item l0; l0 + e at d0 + dir * e
+            U4 wp, wc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int a = dir > 0 ? e : 3 - e;
+                wp.v[a] = stP[l0 + e];
+                wc.v[a] = stC[l0 + e];
+            }
+            const int64_t lo = dir > 0 ? d0 : d0 - 3;
+            *reinterpret_cast<U4 *>(SA + lo) = wp;
+            *reinterpret_cast<U4 *>(CTX + lo) = wc;
+        } else {
+            for (uint32_t li = l0; li < l0 + 4u && li < total; li++) {
+                const uint32_t c2 = li < coff[1] ? 0u : (li < coff[2] ? 1u : (li < coff[3] ? 2u : 3u));
+                const uint32_t toff = ex[(uint64_t)c2 * tiles + blockIdx.x] - ex[(uint64_t)c2 * tiles];
+                const uint32_t cstart = c2 == 0 ? coff[0] : (c2 == 1 ? coff[1] : (c2 == 2 ? coff[2] : coff[3]));
+                const int64_t dp = c2 == 0 ? dst.p[0] : (c2 == 1 ? dst.p[1] : (c2 == 2 ? dst.p[2] : dst.p[3]));
+                const int64_t d = dp + (int64_t)dir * (int64_t)(toff + (li - cstart));
+                SA[d] = stP[li];
+                CTX[d] = stC[li];
+            }
+        }
     }
 }
 
