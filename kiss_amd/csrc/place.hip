@@ -111,26 +111,64 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_order(const uint64_t *__res
 }
 
 // merged list + context words.  near_sidx: insertion indexes sorted ascending (E entries)
+__device__ __forceinline__ uint32_t near_shift(const uint32_t *__restrict__ near_sidx, uint32_t E, uint64_t i)
+{
+    uint32_t lo = 0, hi = E; // #{e : near_idx[e] <= i}
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (near_sidx[mid] <= i) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// a thread moves four consecutive entries (16-byte loads; 16-byte stores when no near-end suffix lands among them)
 __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__restrict__ pk,
                                                          const uint32_t *__restrict__ far_sorted,
                                                          const uint32_t *__restrict__ far_ctx, uint64_t m_far,
                                                          const uint32_t *__restrict__ near_sidx, uint32_t E,
                                                          uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC)
 {
-    uint64_t i = (uint64_t)blockIdx.x * PL_THREADS + threadIdx.x;
-    if (i >= m_far) return;
-    // shift = #{e : near_idx[e] <= i}
-    uint32_t lo = 0, hi = E;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (near_sidx[mid] <= i) lo = mid + 1;
-        else hi = mid;
+    struct __attribute__((packed, aligned(4))) U4 {
+        uint32_t v[4];
+    };
+    const uint64_t i0 = ((uint64_t)blockIdx.x * PL_THREADS + threadIdx.x) * 4;
+    if (i0 >= m_far) return;
+    if (i0 + 4 <= m_far) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(far_sorted + i0);
+        const uint4 c = *reinterpret_cast<const uint4 *>(far_ctx + i0);
+        uint32_t xs[4] = {x.x, x.y, x.z, x.w}, cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (cs[e] == 0) cs[e] = kiss_load_ctx(pk, xs[e]); // not unique after round 0: gather
+        const uint32_t lo0 = near_shift(near_sidx, E, i0), lo3 = E ? near_shift(near_sidx, E, i0 + 3) : 0u;
+        if (lo0 == lo3) {
+            U4 wp, wc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                wp.v[e] = xs[e];
+                wc.v[e] = cs[e];
+            }
+            *reinterpret_cast<U4 *>(lmsP + i0 + lo0) = wp;
+            *reinterpret_cast<U4 *>(lmsC + i0 + lo0) = wc;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t lo = near_shift(near_sidx, E, i0 + e);
+                lmsP[i0 + e + lo] = xs[e];
+                lmsC[i0 + e + lo] = cs[e];
+            }
+        }
+    } else {
+        for (uint64_t i = i0; i < m_far; i++) {
+            const uint32_t lo = near_shift(near_sidx, E, i);
+            const uint32_t x = far_sorted[i];
+            uint32_t c = far_ctx[i];
+            if (c == 0) c = kiss_load_ctx(pk, x);
+            lmsP[i + lo] = x;
+            lmsC[i + lo] = c;
+        }
     }
-    uint32_t x = far_sorted[i];
-    uint32_t c = far_ctx[i]; // from the key payload when round 0 already made the suffix unique, else 0
-    if (c == 0) c = kiss_load_ctx(pk, x);
-    lmsP[i + lo] = x;
-    lmsC[i + lo] = c;
 }
 
 __global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__restrict__ pk,
@@ -175,13 +213,13 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         KCHECK(hipMemcpyAsync(ctx->near_pos, idx.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         KCHECK(hipStreamSynchronize(ctx->stream)); // idx goes out of scope
         if (m_far)
-            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0,
+            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0,
                                ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_pos, E,
                                ctx->lmsP, ctx->lmsC);
         hipLaunchKernelGGL(k_merge_near, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
                            ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
     } else {
-        hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(m_far, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
+        hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
                            ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP,
                            ctx->lmsC);
     }

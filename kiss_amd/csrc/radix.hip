@@ -126,6 +126,23 @@ __global__ __launch_bounds__(RX_THREADS) void k_radix_hist_all(const uint64_t *_
             atomicAdd(&bins[d], next - lane_id());
         }
     };
+    if (!HAS_SEG) { // unsorted input: order is irrelevant, two keys per 16-byte load
+        const uint64_t tb = (uint64_t)blockIdx.x * RX_TILE;
+#pragma unroll 2
+        for (int j = 0; j < RX_ITEMS / 2; j++) {
+            const uint64_t g = tb + (uint64_t)j * (2 * RX_THREADS) + 2 * threadIdx.x;
+            if (g + 1 < count) {
+                const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + g);
+                for (int p = 0; p < n_key; p++) {
+                    atomicAdd(&mine[p * 256 + ((uint32_t)(kk.x >> (key_shift0 + 8 * p)) & 255u)], 1u);
+                    atomicAdd(&mine[p * 256 + ((uint32_t)(kk.y >> (key_shift0 + 8 * p)) & 255u)], 1u);
+                }
+            } else if (g < count) {
+                const uint64_t k = key[g];
+                for (int p = 0; p < n_key; p++) atomicAdd(&mine[p * 256 + ((uint32_t)(k >> (key_shift0 + 8 * p)) & 255u)], 1u);
+            }
+        }
+    } else
 #pragma unroll 2
     for (int j = 0; j < RX_ITEMS; j++) {
         const uint64_t g = base + (uint64_t)j * RX_THREADS;
