@@ -419,6 +419,166 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
     }
 }
 
+// ---- round 0 (keys only, slot = index): the same flag + compaction with 16-byte accesses ----------------------
+// A thread owns FC_ITEMS consecutive items (two keys per load, four positions per load); survivor ranks come from a
+// wave prefix of the per-thread counts.  Every slot gets its position (a tied suffix's slot is rewritten when it
+// retires later) and its context word (0 while tied), so the stores are plain 16-byte streams.
+__device__ __forceinline__ void fc0_load(const uint64_t *__restrict__ key, uint64_t i0, uint64_t count, int cmp_shift,
+                                         uint64_t k[FC_ITEMS + 2], uint32_t &valid)
+{
+    // k[0] = key before my first item, k[1..FC_ITEMS] = my items, k[FC_ITEMS + 1] = key after; all >> cmp_shift
+    valid = i0 >= count ? 0u : (count - i0 >= FC_ITEMS ? (uint32_t)FC_ITEMS : (uint32_t)(count - i0));
+    if (valid == FC_ITEMS) {
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 2; q++) {
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + i0 + 2 * q);
+            k[1 + 2 * q] = kk.x >> cmp_shift;
+            k[2 + 2 * q] = kk.y >> cmp_shift;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++) k[1 + e] = (uint32_t)e < valid ? (key[i0 + e] >> cmp_shift) : 0ull;
+    }
+    k[0] = (valid && i0 > 0) ? (key[i0 - 1] >> cmp_shift) : 0ull;
+    k[FC_ITEMS + 1] = (valid && i0 + FC_ITEMS < count) ? (key[i0 + FC_ITEMS] >> cmp_shift) : 0ull;
+}
+
+__device__ __forceinline__ void fc0_flags(const uint64_t k[FC_ITEMS + 2], uint64_t i0, uint64_t count, uint32_t valid,
+                                          uint32_t &survmask, uint32_t &headmask)
+{
+    survmask = headmask = 0;
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((uint32_t)e < valid) {
+            const uint64_t i = i0 + (uint64_t)e;
+            const bool head = i == 0 || k[e] != k[e + 1];
+            const bool nhead = i + 1 == count || k[e + 2] != k[e + 1];
+            const bool surv = !(head && nhead);
+            survmask |= (surv ? 1u : 0u) << e;
+            headmask |= ((surv && head) ? 1u : 0u) << e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_fc0_count(const uint64_t *__restrict__ key, uint64_t count, int cmp_shift,
+                                                         uint64_t *__restrict__ tcnt)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint64_t k[FC_ITEMS + 2];
+    uint32_t valid, sm, hm;
+    fc0_load(key, i0, count, cmp_shift, k, valid);
+    fc0_flags(k, i0, count, valid, sm, hm);
+    uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ns += __shfl_xor(ns, d, 64);
+        nh += __shfl_xor(nh, d, 64);
+    }
+    if (lane_id() == 0) {
+        ws[threadIdx.x >> 6][0] = ns;
+        ws[threadIdx.x >> 6][1] = nh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t a = 0, b = 0;
+        for (int w = 0; w < FC_THREADS / 64; w++) {
+            a += ws[w][0];
+            b += ws[w][1];
+        }
+        tcnt[blockIdx.x] = (a << 32) | b;
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__restrict__ key,
+                                                           const uint32_t *__restrict__ pos, uint64_t count,
+                                                           int cmp_shift, const uint64_t *__restrict__ tex,
+                                                           uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
+                                                           uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
+                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ octx)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint64_t k[FC_ITEMS + 2];
+    uint32_t valid, sm, hm;
+    fc0_load(key, i0, count, cmp_shift, k, valid);
+    fc0_flags(k, i0, count, valid, sm, hm);
+    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+    uint32_t is = ns, ih = nh; // inclusive wave prefixes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
+        if ((int)lane_id() >= d) {
+            is += os;
+            ih += oh;
+        }
+    }
+    if (lane_id() == 63) {
+        ws[wave][0] = is;
+        ws[wave][1] = ih;
+    }
+    __syncthreads();
+    const uint64_t te = tex[blockIdx.x];
+    uint32_t bs = (uint32_t)(te >> 32) + (is - ns), bh = (uint32_t)(te & 0xFFFFFFFFull) + (ih - nh);
+    for (int w = 0; w < wave; w++) {
+        bs += ws[w][0];
+        bh += ws[w][1];
+    }
+    if (valid == 0) return;
+    // payload of my keys: the low KISS_KEY_CTX bits (cmp_shift >= 24 in round 0) -- reload the raw keys' low words
+    uint32_t p[FC_ITEMS], cw[FC_ITEMS];
+    if (valid == FC_ITEMS) {
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 4; q++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(pos + i0 + 4 * q);
+            p[4 * q] = t.x;
+            p[4 * q + 1] = t.y;
+            p[4 * q + 2] = t.z;
+            p[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 2; q++) {
+            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + i0 + 2 * q);
+            cw[2 * q] = (uint32_t)(kk.x & KISS_KEY_CTX_MASK);
+            cw[2 * q + 1] = (uint32_t)(kk.y & KISS_KEY_CTX_MASK);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++) {
+            p[e] = (uint32_t)e < valid ? pos[i0 + e] : 0u;
+            cw[e] = (uint32_t)e < valid ? (uint32_t)(key[i0 + e] & KISS_KEY_CTX_MASK) : 0u;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((sm >> e) & 1u) {
+            const uint32_t ni = bs++;
+            if ((hm >> e) & 1u) bh++;
+            const uint32_t sid = bh - 1u; // heads up to and including this item's own segment head
+            npos[ni] = p[e];
+            nslot[ni] = (uint32_t)(i0 + e);
+            nseg[ni] = sid;
+            if ((hm >> e) & 1u) nsegstart[sid] = ni;
+            cw[e] = 0; // tied so far: its context word is gathered at placement
+        }
+    }
+    if (valid == FC_ITEMS) {
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 4; q++) {
+            *reinterpret_cast<uint4 *>(out + i0 + 4 * q) = make_uint4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+            *reinterpret_cast<uint4 *>(octx + i0 + 4 * q) = make_uint4(cw[4 * q], cw[4 * q + 1], cw[4 * q + 2], cw[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++)
+            if ((uint32_t)e < valid) {
+                out[i0 + e] = p[e];
+                octx[i0 + e] = cw[e];
+            }
+    }
+}
+
 __global__ void k_fc_total(const uint64_t *__restrict__ tcnt, const uint64_t *__restrict__ tex, uint64_t tiles,
                            uint64_t *__restrict__ total)
 {
@@ -436,8 +596,11 @@ int fc_count(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, uint64
     uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles;
     {
         KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        hipLaunchKernelGGL((k_fc_count<SRC>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
-                           cmp_shift, last_round, tcnt);
+        if (SRC == FC_KEY && !last_round)
+            hipLaunchKernelGGL(k_fc0_count, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, count, cmp_shift, tcnt);
+        else
+            hipLaunchKernelGGL((k_fc_count<SRC>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
+                               cmp_shift, last_round, tcnt);
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_scan_u64(ctx, tcnt, tex, tiles));
@@ -462,8 +625,12 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     const uint64_t tiles = div_up(count, FC_TILE);
     const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
     KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-    hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
-                       pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa, octx);
+    if (SRC == FC_KEY && !HAS_SLOT && !last_round && out && octx && !isa && cmp_shift >= 24)
+        hipLaunchKernelGGL(k_fc0_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, pos, count, cmp_shift, tex,
+                           npos, nslot, nseg, nsegstart, out, octx);
+    else
+        hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
+                           pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa, octx);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
