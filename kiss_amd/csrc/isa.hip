@@ -42,18 +42,41 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
     __syncthreads();
     uint64_t pr[IB_ITEMS];
     uint32_t rk[IB_ITEMS];
+    // the order of the items inside a bin is irrelevant: a thread takes IB_ITEMS consecutive ones (16-byte loads)
+    const uint32_t l0 = threadIdx.x * IB_ITEMS;
+    if (l0 + IB_ITEMS <= tile_count) {
+        const uint64_t g0 = tile_base + l0;
+        if (FROM_SA) {
 #pragma unroll
-    for (int j = 0; j < IB_ITEMS; j++) {
-        const uint32_t li = threadIdx.x + (uint32_t)j * IB_THREADS;
-        if (li < tile_count) {
-            const uint64_t g = tile_base + li;
-            pr[j] = FROM_SA ? (((uint64_t)SA[base + g] << 32) | (base + g)) : pairs_in[g];
-        } else
-            pr[j] = 0;
+            for (int q = 0; q < IB_ITEMS / 4; q++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(SA + base + g0 + 4 * q);
+                pr[4 * q] = ((uint64_t)t.x << 32) | (base + g0 + 4 * q);
+                pr[4 * q + 1] = ((uint64_t)t.y << 32) | (base + g0 + 4 * q + 1);
+                pr[4 * q + 2] = ((uint64_t)t.z << 32) | (base + g0 + 4 * q + 2);
+                pr[4 * q + 3] = ((uint64_t)t.w << 32) | (base + g0 + 4 * q + 3);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < IB_ITEMS / 2; q++) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(pairs_in + g0 + 2 * q);
+                pr[2 * q] = t.x;
+                pr[2 * q + 1] = t.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < IB_ITEMS; j++) {
+            const uint32_t li = l0 + (uint32_t)j;
+            if (li < tile_count) {
+                const uint64_t g = tile_base + li;
+                pr[j] = FROM_SA ? (((uint64_t)SA[base + g] << 32) | (base + g)) : pairs_in[g];
+            } else
+                pr[j] = 0;
+        }
     }
 #pragma unroll
     for (int j = 0; j < IB_ITEMS; j++) {
-        const uint32_t li = threadIdx.x + (uint32_t)j * IB_THREADS;
+        const uint32_t li = l0 + (uint32_t)j;
         if (li < tile_count) {
             const uint32_t d = (uint32_t)(pr[j] >> (32 + shift)) & 255u;
             // rank inside (tile, bin), < 16384.  A wave whose 64 items share one bin (sorted stretches of SA, e.g.
