@@ -579,6 +579,111 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
     }
 }
 
+// ---- tie flags as bytes (the doubling phase's first compaction over all n + 1 suffixes): 8 flags per load, and the
+// suffix array is read only for the few entries that are tied ------------------------------------------------
+__device__ __forceinline__ void fch_flags(const uint8_t *__restrict__ hb, uint64_t i0, uint64_t count, uint32_t &valid,
+                                          uint32_t &survmask, uint32_t &headmask)
+{
+    valid = i0 >= count ? 0u : (count - i0 >= FC_ITEMS ? (uint32_t)FC_ITEMS : (uint32_t)(count - i0));
+    survmask = headmask = 0;
+    if (!valid) return;
+    uint8_t h[FC_ITEMS + 1];
+    if (valid == FC_ITEMS) {
+        const uint64_t w = *reinterpret_cast<const uint64_t *>(hb + i0);
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++) h[e] = (uint8_t)(w >> (8 * e));
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++) h[e] = (uint32_t)e < valid ? hb[i0 + e] : (uint8_t)1;
+    }
+    h[FC_ITEMS] = i0 + FC_ITEMS < count ? hb[i0 + FC_ITEMS] : (uint8_t)1;
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((uint32_t)e < valid) {
+            const uint64_t i = i0 + (uint64_t)e;
+            const bool head = i == 0 || h[e] != 0;
+            const bool nhead = i + 1 == count || h[e + 1] != 0;
+            const bool surv = !(head && nhead);
+            survmask |= (surv ? 1u : 0u) << e;
+            headmask |= ((surv && head) ? 1u : 0u) << e;
+        }
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_fch_count(const uint8_t *__restrict__ hb, uint64_t count,
+                                                         uint64_t *__restrict__ tcnt)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint32_t valid, sm, hm;
+    fch_flags(hb, i0, count, valid, sm, hm);
+    uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ns += __shfl_xor(ns, d, 64);
+        nh += __shfl_xor(nh, d, 64);
+    }
+    if (lane_id() == 0) {
+        ws[threadIdx.x >> 6][0] = ns;
+        ws[threadIdx.x >> 6][1] = nh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t a = 0, b = 0;
+        for (int w = 0; w < FC_THREADS / 64; w++) {
+            a += ws[w][0];
+            b += ws[w][1];
+        }
+        tcnt[blockIdx.x] = (a << 32) | b;
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_fch_compact(const uint8_t *__restrict__ hb,
+                                                           const uint32_t *__restrict__ pos, uint64_t count,
+                                                           const uint64_t *__restrict__ tex, uint32_t *__restrict__ npos,
+                                                           uint32_t *__restrict__ nslot, uint32_t *__restrict__ nseg,
+                                                           uint32_t *__restrict__ nsegstart)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint32_t valid, sm, hm;
+    fch_flags(hb, i0, count, valid, sm, hm);
+    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+    uint32_t is = ns, ih = nh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
+        if ((int)lane_id() >= d) {
+            is += os;
+            ih += oh;
+        }
+    }
+    if (lane_id() == 63) {
+        ws[wave][0] = is;
+        ws[wave][1] = ih;
+    }
+    __syncthreads();
+    const uint64_t te = tex[blockIdx.x];
+    uint32_t bs = (uint32_t)(te >> 32) + (is - ns), bh = (uint32_t)(te & 0xFFFFFFFFull) + (ih - nh);
+    for (int w = 0; w < wave; w++) {
+        bs += ws[w][0];
+        bh += ws[w][1];
+    }
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((sm >> e) & 1u) {
+            const uint32_t ni = bs++;
+            if ((hm >> e) & 1u) bh++;
+            const uint32_t sid = bh - 1u;
+            npos[ni] = pos[i0 + e];
+            nslot[ni] = (uint32_t)(i0 + e);
+            nseg[ni] = sid;
+            if ((hm >> e) & 1u) nsegstart[sid] = ni;
+        }
+    }
+}
+
 __global__ void k_fc_total(const uint64_t *__restrict__ tcnt, const uint64_t *__restrict__ tex, uint64_t tiles,
                            uint64_t *__restrict__ total)
 {
@@ -596,7 +701,10 @@ int fc_count(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, uint64
     uint64_t *tcnt = ctx->flags, *tex = ctx->flags + tiles;
     {
         KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-        if (SRC == FC_KEY && !last_round)
+        if (SRC == FC_HEADS)
+            hipLaunchKernelGGL(k_fch_count, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream,
+                               reinterpret_cast<const uint8_t *>(key), count, tcnt);
+        else if (SRC == FC_KEY && !last_round)
             hipLaunchKernelGGL(k_fc0_count, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, count, cmp_shift, tcnt);
         else
             hipLaunchKernelGGL((k_fc_count<SRC>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg, count,
@@ -625,7 +733,10 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     const uint64_t tiles = div_up(count, FC_TILE);
     const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
     KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-    if (SRC == FC_KEY && !HAS_SLOT && !last_round && out && octx && !isa && cmp_shift >= 24)
+    if (SRC == FC_HEADS && !HAS_SLOT && !out && !isa && !octx)
+        hipLaunchKernelGGL(k_fch_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream,
+                           reinterpret_cast<const uint8_t *>(key), pos, count, tex, npos, nslot, nseg, nsegstart);
+    else if (SRC == FC_KEY && !HAS_SLOT && !last_round && out && octx && !isa && cmp_shift >= 24)
         hipLaunchKernelGGL(k_fc0_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, pos, count, cmp_shift, tex,
                            npos, nslot, nseg, nsegstart, out, octx);
     else
