@@ -122,6 +122,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     }
     __syncthreads();
     if (threadIdx.x < 4) counts[(uint64_t)threadIdx.x * tiles + blockIdx.x] = tc[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 4) counts[4 * tiles] = 0; // the extra last entry of the scan input
 }
 
 struct DstPos {
@@ -132,9 +133,12 @@ struct DstPos {
 __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                               uint32_t *srcC, int64_t beg, uint64_t N, int dir,
                                                               uint32_t emitmask, const uint32_t *__restrict__ ex,
-                                                              uint64_t tiles, DstPos dst, uint32_t *SA, uint32_t *CTX)
+                                                              uint64_t tiles, DstPos dst, uint32_t *SA, uint32_t *CTX,
+                                                              uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t wtot[IN_WAVES][4];
+    // items appended per class = differences of the scanned counts (4 * tiles + 1 entries)
+    if (blockIdx.x == 0 && threadIdx.x < 4) totals[threadIdx.x] = ex[(uint64_t)(threadIdx.x + 1) * tiles] - ex[(uint64_t)threadIdx.x * tiles];
     const int wave = threadIdx.x >> 6;
     // A thread owns IN_ITEMS consecutive items (item order = thread order, then order inside the thread), read with
     // 16-byte loads; its rank inside a class = items of that class in lower lanes (wave prefix of the per-lane
@@ -278,12 +282,6 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
     }
 }
 
-// totals per class from the scanned counts (4*tiles+1 entries, the extra last input entry is 0)
-__global__ void k_induce_totals(const uint32_t *__restrict__ ex, uint64_t tiles, uint32_t *__restrict__ out)
-{
-    if (threadIdx.x < 4) out[threadIdx.x] = ex[(uint64_t)(threadIdx.x + 1) * tiles] - ex[(uint64_t)threadIdx.x * tiles];
-}
-
 // ---- single-workgroup chain kernel -----------------------------------------------------
 // Processes one source segment and, when selfclass >= 0, keeps processing what it appended to that
 // class until nothing is appended any more.  out[0..3] = items appended per class, out[4] = rounds.
@@ -397,7 +395,6 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         if (4 * tiles + 1 > ctx->ind_tiles_cap) return KINTERNAL();
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
-            KTRY(kiss_zero_u32(ctx, ctx->ind_counts + 4 * tiles, 1));
             hipLaunchKernelGGL(k_induce_count, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
                                srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles);
             KCHECK(hipGetLastError());
@@ -406,9 +403,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SCATTER, N);
             hipLaunchKernelGGL(k_induce_scatter, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                               srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX);
-            hipLaunchKernelGGL(k_induce_totals, dim3(1), dim3(64), 0, ctx->stream, ctx->ind_counts, tiles,
-                               ctx->d_small);
+                               srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small);
             KCHECK(hipGetLastError());
         }
         KCHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
