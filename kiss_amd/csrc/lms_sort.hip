@@ -424,7 +424,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
 // wave prefix of the per-thread counts.  Every slot gets its position (a tied suffix's slot is rewritten when it
 // retires later) and its context word (0 while tied), so the stores are plain 16-byte streams.
 __device__ __forceinline__ void fc0_load(const uint64_t *__restrict__ key, uint64_t i0, uint64_t count, int cmp_shift,
-                                         uint64_t k[FC_ITEMS + 2], uint32_t &valid)
+                                         uint64_t k[FC_ITEMS + 2], uint32_t &valid, uint32_t *low = nullptr)
 {
     // k[0] = key before my first item, k[1..FC_ITEMS] = my items, k[FC_ITEMS + 1] = key after; all >> cmp_shift
     valid = i0 >= count ? 0u : (count - i0 >= FC_ITEMS ? (uint32_t)FC_ITEMS : (uint32_t)(count - i0));
@@ -434,10 +434,18 @@ __device__ __forceinline__ void fc0_load(const uint64_t *__restrict__ key, uint6
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + i0 + 2 * q);
             k[1 + 2 * q] = kk.x >> cmp_shift;
             k[2 + 2 * q] = kk.y >> cmp_shift;
+            if (low) { // the payload bits below the compared ones
+                low[2 * q] = (uint32_t)(kk.x & KISS_KEY_CTX_MASK);
+                low[2 * q + 1] = (uint32_t)(kk.y & KISS_KEY_CTX_MASK);
+            }
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++) k[1 + e] = (uint32_t)e < valid ? (key[i0 + e] >> cmp_shift) : 0ull;
+        for (int e = 0; e < FC_ITEMS; e++) {
+            const uint64_t kk = (uint32_t)e < valid ? key[i0 + e] : 0ull;
+            k[1 + e] = kk >> cmp_shift;
+            if (low) low[e] = (uint32_t)(kk & KISS_KEY_CTX_MASK);
+        }
     }
     k[0] = (valid && i0 > 0) ? (key[i0 - 1] >> cmp_shift) : 0ull;
     k[FC_ITEMS + 1] = (valid && i0 + FC_ITEMS < count) ? (key[i0 + FC_ITEMS] >> cmp_shift) : 0ull;
@@ -502,7 +510,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
     const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
     uint64_t k[FC_ITEMS + 2];
     uint32_t valid, sm, hm;
-    fc0_load(key, i0, count, cmp_shift, k, valid);
+    uint32_t p[FC_ITEMS], cw[FC_ITEMS];
+    fc0_load(key, i0, count, cmp_shift, k, valid, cw);
     fc0_flags(k, i0, count, valid, sm, hm);
     const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
     uint32_t is = ns, ih = nh; // inclusive wave prefixes
@@ -526,8 +535,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
         bh += ws[w][1];
     }
     if (valid == 0) return;
-    // payload of my keys: the low KISS_KEY_CTX bits (cmp_shift >= 24 in round 0) -- reload the raw keys' low words
-    uint32_t p[FC_ITEMS], cw[FC_ITEMS];
+    // cw = payload of my keys: the low KISS_KEY_CTX bits (cmp_shift >= 24 in round 0), kept from the one key load
     if (valid == FC_ITEMS) {
 #pragma unroll
         for (int q = 0; q < FC_ITEMS / 4; q++) {
@@ -537,18 +545,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
             p[4 * q + 2] = t.z;
             p[4 * q + 3] = t.w;
         }
-#pragma unroll
-        for (int q = 0; q < FC_ITEMS / 2; q++) {
-            const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(key + i0 + 2 * q);
-            cw[2 * q] = (uint32_t)(kk.x & KISS_KEY_CTX_MASK);
-            cw[2 * q + 1] = (uint32_t)(kk.y & KISS_KEY_CTX_MASK);
-        }
     } else {
 #pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++) {
-            p[e] = (uint32_t)e < valid ? pos[i0 + e] : 0u;
-            cw[e] = (uint32_t)e < valid ? (uint32_t)(key[i0 + e] & KISS_KEY_CTX_MASK) : 0u;
-        }
+        for (int e = 0; e < FC_ITEMS; e++) p[e] = (uint32_t)e < valid ? pos[i0 + e] : 0u;
     }
 #pragma unroll
     for (int e = 0; e < FC_ITEMS; e++) {
