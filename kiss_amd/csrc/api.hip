@@ -493,6 +493,7 @@ int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, 
     int res = 0;
     KTRY(kiss_radix_sort(ctx, rb, count, key_lo_bit, 0, &res));
     KTRY(kiss_radix_check(ctx));
+    ktimer_collect(ctx); // kernel-class times of this call show up in kiss_hip_get_stats (tools/radix_probe.py)
     KCHECK(hipMemcpy(keys, rb.key[res], count * 8, hipMemcpyDeviceToHost));
     KCHECK(hipMemcpy(pos, rb.pos[res], count * 4, hipMemcpyDeviceToHost));
     return KISS_HIP_OK;
