@@ -294,7 +294,7 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
         uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const uint32_t sel = 0u - ((d >> b) & 1u);
+            const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1); // 0 or ~0: one v_bfe_i32
             const uint64_t bm = __ballot(sel != 0u);
             plo &= ~((uint32_t)bm ^ sel);
             phi &= ~((uint32_t)(bm >> 32) ^ sel);
