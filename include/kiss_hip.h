@@ -242,6 +242,14 @@ int kiss_hip_fmi_query_batch_host(const kiss_hip_fmi_view *fmi, const uint8_t *p
                                   uint32_t *beg, uint32_t *end, uint64_t *hit_count_total, uint64_t *checksum,
                                   uint32_t *offsets, uint64_t *offsets_index, uint64_t offsets_capacity, int device);
 
+/* ---- General alphabet (bytes): exact suffix array ---------------------------------
+ * Replaces KISS1Sorter::get_suffix_array -> kiss1_suffix_array (kiss1_core.hpp:270-311), reachable only from the
+ * reference's tests / experiments.  For that entry only the k-order property is defined (its comparator has no
+ * index tie-break); the exact suffix array (shorter suffix first on a tie, SA[0] = n, n + 1 entries) satisfies it for
+ * every k.  7-character keys + rank doubling over all suffixes; no induction.  n <= ctx max_n. */
+int kiss_hip_suffix_sort_u8(const uint8_t *S, uint64_t n, uint32_t *SA, int device);
+int kiss_hip_ctx_suffix_sort_u8_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t *d_SA, void *stream);
+
 /* ---- FASTA / plain-text input parsed on the device (replaces read_sequence, include/utils/io.hpp:6-18, and the
  * `c % 4` of command/suffix_sort.hpp:33; record rules of biovoltron/file_io/fasta.hpp:117-151) ------------------
  * The file is FASTA iff its first byte is '>'.  Header lines are dropped, every other byte except '\n' is a base:

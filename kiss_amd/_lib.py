@@ -110,6 +110,10 @@ def load():
     lib.kiss_hip_ctx_parse_text_dev.argtypes = [vp, vp, u64, vp, ctypes.POINTER(u64), vp]
     lib.kiss_hip_ctx_load_text_file.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(vp), ctypes.POINTER(u64)]
     lib.kiss_hip_copy_to_host.argtypes = [vp, vp, u64]
+    lib.kiss_hip_suffix_sort_u8.argtypes = [vp, u64, vp, ctypes.c_int]
+    lib.kiss_hip_suffix_sort_u8.restype = ctypes.c_int
+    lib.kiss_hip_ctx_suffix_sort_u8_dev.argtypes = [vp, vp, u64, vp, vp]
+    lib.kiss_hip_ctx_suffix_sort_u8_dev.restype = ctypes.c_int
     lib.kiss_hip_free_dev.argtypes = [vp]
     lib.kiss_hip_alloc_dev.argtypes = [ctypes.POINTER(vp), u64]
     lib.kiss_hip_alloc_dev.restype = ctypes.c_int
@@ -143,5 +147,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_stage_sort", "kiss_hip_stage_induce",
     "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
     "kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file", "kiss_hip_copy_to_host",
-    "kiss_hip_free_dev", "kiss_hip_alloc_dev",
+    "kiss_hip_free_dev", "kiss_hip_alloc_dev", "kiss_hip_suffix_sort_u8", "kiss_hip_ctx_suffix_sort_u8_dev",
 ]

@@ -61,6 +61,17 @@ struct KissHipSorter {
                                    std::size_t num_threads = std::thread::hardware_concurrency()) {
     return get_suffix_array_dna(prepare_aligned_ref(ref), k, num_threads);
   }
+
+  // general alphabet (bytes), kiss1_sorter.hpp:36-44 -> kiss1_suffix_array (kiss1_core.hpp:270-311): the reference
+  // defines only the k-order property there; this returns the exact suffix array, which has it for every k
+  static SA_t get_suffix_array(const std::ranges::random_access_range auto& ref, size_type /*k*/ = 256u,
+                               std::size_t /*num_threads*/ = std::thread::hardware_concurrency()) {
+    const auto S = prepare_aligned_ref(ref);
+    SA_t SA(S.size() + 1);
+    check(kiss_hip_suffix_sort_u8(S.data(), S.size(), reinterpret_cast<std::uint32_t*>(SA.data()), device()),
+          "kiss_hip_suffix_sort_u8");
+    return SA;
+  }
 };
 
 // KISS2 (PREFIX_DOUBLING): defined for k >= n only (exact suffix array), see DESIGN.md section 8

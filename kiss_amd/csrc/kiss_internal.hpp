@@ -144,7 +144,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 constexpr uint64_t KISS_EXACT_MSD_MAX_DEPTH = 32768;
 constexpr int KISS_INTERNAL_TOO_DEEP = 1000; // never crosses the ABI
 // exact order from an h0-ordered SA by rank doubling over the full suffix array (lms_sort.hip)
-int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA);
+int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, uint8_t *heads_in = nullptr);
 // isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)
 int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC

@@ -1127,19 +1127,21 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_ranks(const uint32_t *__r
 
 } // namespace
 
-int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA)
+int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, uint8_t *heads_in)
 {
-    if (h0 < 32 || n < h0) return KINTERNAL();
+    // heads_in == nullptr: DNA, SA ordered by h0 >= 32 bases, ties found by comparing the packed text;
+    // heads_in != nullptr: the caller knows the groups already (general alphabet: equal 7-character keys)
+    if ((!heads_in && h0 < 32) || h0 == 0 || n < h0) return KINTERNAL();
     const uint64_t total = n + 1;
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
     uint32_t *isa = ctx->CTX; // the induction's context words are dead by now: (n + 2) u32
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
-    uint8_t *heads = nullptr;
-    KCHECK(hipMalloc((void **)&heads, total));
+    uint8_t *heads = heads_in;
+    if (!heads) KCHECK(hipMalloc((void **)&heads, total));
     int rc = KISS_HIP_OK;
     do {
-        {
+        if (!heads_in) {
             KTimer t(ctx, KISS_HIP_K_GROUP_HEADS, total);
             hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
                                total, h0, heads);
@@ -1260,6 +1262,6 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
         ctx->last_hip_error = (int)e;
         rc = KISS_HIP_E_HIP;
     }
-    (void)hipFree(heads);
+    if (!heads_in) (void)hipFree(heads);
     return rc;
 }

@@ -141,6 +141,18 @@ class KISS1Sorter:
         return SA
 
 
+def suffix_array_bytes(data, device=0):
+    """Exact suffix array (uint32, n + 1 entries, SA[0] = n) of a text over the byte alphabet: the general-alphabet
+    entry of the reference facade, KISS1Sorter::get_suffix_array (kiss1_sorter.hpp:28-34 -> kiss1_core.hpp:270-311)."""
+    S = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data,
+                             dtype=np.uint8)
+    SA = np.empty(S.size + 1, dtype=np.uint32)
+    lib = _lib.load()
+    _check(lib.kiss_hip_suffix_sort_u8(S.ctypes.data if S.size else None, S.size, SA.ctypes.data, int(device)),
+           "kiss_hip_suffix_sort_u8")
+    return SA
+
+
 class KISS2Sorter(KISS1Sorter):
     """PREFIX_DOUBLING (kiss2_sorter.hpp:8-50); defined for k >= n (exact suffix array) only."""
     algo = _lib.ALGO_PREFIX_DOUBLING

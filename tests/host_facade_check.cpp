@@ -13,7 +13,8 @@ int main(int argc, char**) {
   if (argc > 100) {  // never executed on a box without a GPU
     auto sa = biovoltron::KissHipSorter<>::get_suffix_array_dna(S, 256u, 1);
     auto sb = biovoltron::KissHipSorter2<>::get_suffix_array_dna(S);
-    return (int)(sa.size() + sb.size());
+    auto sc = biovoltron::KissHipSorter<>::get_suffix_array(std::string_view("general alphabet"), 256u, 1);
+    return (int)(sa.size() + sb.size() + sc.size());
   }
   return 0;
 }
