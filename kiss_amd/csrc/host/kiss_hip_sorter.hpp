@@ -56,13 +56,13 @@ struct KissHipSorter {
     return SA;
   }
 
-  // range overload, kiss1_sorter.hpp:28-34
+  // range overload, kiss1_sorter.hpp:10-18
   static SA_t get_suffix_array_dna(const std::ranges::random_access_range auto& ref, size_type k = 256u,
                                    std::size_t num_threads = std::thread::hardware_concurrency()) {
     return get_suffix_array_dna(prepare_aligned_ref(ref), k, num_threads);
   }
 
-  // general alphabet (bytes), kiss1_sorter.hpp:36-44 -> kiss1_suffix_array (kiss1_core.hpp:270-311): the reference
+  // general alphabet (bytes), kiss1_sorter.hpp:28-45 -> kiss1_suffix_array (kiss1_core.hpp:270-311): the reference
   // defines only the k-order property there; this returns the exact suffix array, which has it for every k
   static SA_t get_suffix_array(const std::ranges::random_access_range auto& ref, size_type /*k*/ = 256u,
                                std::size_t /*num_threads*/ = std::thread::hardware_concurrency()) {

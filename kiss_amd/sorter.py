@@ -143,7 +143,7 @@ class KISS1Sorter:
 
 def suffix_array_bytes(data, device=0):
     """Exact suffix array (uint32, n + 1 entries, SA[0] = n) of a text over the byte alphabet: the general-alphabet
-    entry of the reference facade, KISS1Sorter::get_suffix_array (kiss1_sorter.hpp:28-34 -> kiss1_core.hpp:270-311)."""
+    entry of the reference facade, KISS1Sorter::get_suffix_array (kiss1_sorter.hpp:28-45 -> kiss1_core.hpp:270-311)."""
     S = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data,
                              dtype=np.uint8)
     SA = np.empty(S.size + 1, dtype=np.uint32)
