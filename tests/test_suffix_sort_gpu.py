@@ -307,3 +307,33 @@ print("variants ok")
     env = dict(os.environ, KISS_HIP_NO_ONESWEEP="1", KISS_HIP_TCAP0="1500", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_two_contexts_concurrently(oracle):
+    # "thread-safe per distinct ctx": two host threads, each with its own workspace and stream, sort different
+    # texts at the same time on the same device (ctypes releases the GIL during the calls)
+    import threading
+    import kiss_amd
+    texts = [gen.genome_like(400_000, 11), gen.periodic(300_000, 5, 3, 30)]
+    refs = [oracle.suffix_sort(S, 256) for S in texts]
+    refs_exact = [oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED) for S in texts]
+    errors = []
+
+    def work(i):
+        try:
+            c = kiss_amd.Context(max_n=texts[i].size)
+            for _ in range(4):
+                if not np.array_equal(c.suffix_sort(texts[i], 256), refs[i]):
+                    errors.append("thread %d: k = 256 differs" % i)
+                if not np.array_equal(c.suffix_sort(texts[i], kiss_amd.K_UNBOUNDED, algo=1), refs_exact[i]):
+                    errors.append("thread %d: exact differs" % i)
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
