@@ -214,8 +214,16 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                                                         uint32_t *__restrict__ tile_cnt, // count: out; emit: offsets in
                                                         uint32_t *__restrict__ d_counts, uint64_t far_limit,
                                                         uint64_t win_lo, uint64_t win_hi, // only positions in [lo, hi)
-                                                        uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key)
+                                                        uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key,
+                                                        uint32_t *__restrict__ ghist) // emit: round-0 digit histograms
 {
+    // The emit pass also counts the five 8-bit digits round 0 of the LMS sort will scatter on (key bits 24..63 of the
+    // far suffixes), so the radix sort does not read the 7 GB of keys once more just to count them (radix.hip).
+    __shared__ uint32_t hh[EMIT ? KISS_R0_PASSES * 256 : 1];
+    if (EMIT && ghist) {
+        for (uint32_t i = threadIdx.x; i < KISS_R0_PASSES * 256; i += CL_THREADS) hh[i] = 0;
+        __syncthreads();
+    }
     __shared__ uint32_t lds[8];
     __shared__ uint32_t wsum[CL_THREADS / 64 + 1];
     __shared__ uint16_t stage[EMIT ? CL_THREADS * 16 : 1]; // offsets of the tile's LMS positions (<= 16 per word)
@@ -302,10 +310,21 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                 uint64_t pos = tbase + stage[idx];
                 lms_pos[gbase + idx] = (uint32_t)pos;
                 // first 32 bases; the 24 bits round 0 does not sort on carry the preceding 11 bases (kiss_internal.hpp)
-                lms_key[gbase + idx] = (kiss_key32(pk, pos) & ~KISS_KEY_CTX_MASK) | kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
+                const uint64_t key = kiss_key32(pk, pos);
+                lms_key[gbase + idx] = (key & ~KISS_KEY_CTX_MASK) | kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
+                if (ghist && pos <= far_limit) {
+#pragma unroll
+                    for (int p = 0; p < KISS_R0_PASSES; p++)
+                        atomicAdd(&hh[p * 256 + ((uint32_t)(key >> (KISS_R0_SHIFT + 8 * p)) & 255u)], 1u);
+                }
             }
             __syncthreads();
         }
+    }
+    if (EMIT && ghist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < KISS_R0_PASSES * 256; i += CL_THREADS)
+            if (hh[i]) atomicAdd(&ghist[i], hh[i]);
     }
     if (!EMIT) {
 #pragma unroll
@@ -353,7 +372,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
         hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
                            ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, (uint32_t *)nullptr,
-                           (uint64_t *)nullptr);
+                           (uint64_t *)nullptr, (uint32_t *)nullptr);
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_scan_u32(ctx, ctx->tile_cnt, ctx->tile_cnt, tiles));
@@ -364,12 +383,18 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
     ctx->m = m;
     ctx->m_far = none_far ? 0 : ctx->h_pinned[12];
     if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024)); // more LMS suffixes than DNA-typical
+    ctx->rx_ghist_count = 0;
     if (m > 0) {
+        // digit histograms for round 0 ride along when the whole LMS list is emitted (not a window of it)
+        const bool hist = ctx->rx_ghist && ctx->m_far > 1 && win_lo == 0 && win_hi == n;
+        if (hist) KTRY(kiss_zero_u32(ctx, ctx->rx_ghist, 256ull * KISS_R0_PASSES));
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
-        hipLaunchKernelGGL(k_classify<true>, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
+        const unsigned grid = (unsigned)(tiles < 8192 ? tiles : 8192);
+        hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
                            words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi,
-                           ctx->lms_pos, ctx->keyA);
+                           ctx->lms_pos, ctx->keyA, hist ? ctx->rx_ghist : (uint32_t *)nullptr);
         KCHECK(hipGetLastError());
+        if (hist) ctx->rx_ghist_count = ctx->m_far; // consumed (or dropped) by the next kiss_radix_sort call
     }
     return KISS_HIP_OK;
 }

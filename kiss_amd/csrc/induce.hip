@@ -68,61 +68,56 @@ __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__
 }
 
 // ---- pass 1: per-tile class counts ---------------------------------------------------
+// One WAVE per tile (a workgroup = IN_WAVES tiles): counting does not care about order, so a lane takes four
+// consecutive items per step (16-byte loads, all of the tile's steps in flight at once) and keeps the four class
+// counts in 16-bit fields of one 64-bit word (a tile has 2048 items); no LDS, no barrier, no atomic.
 __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                             uint32_t *srcC, int64_t beg, uint64_t N, int dir,
                                                             uint32_t emitmask, uint32_t *__restrict__ counts,
                                                             uint64_t tiles)
 {
-    __shared__ uint32_t tc[4];
-    if (threadIdx.x < 4) tc[threadIdx.x] = 0;
-    __syncthreads();
-    // counting does not care about order: a lane takes IN_ITEMS consecutive items (two 16-byte loads, 4-byte aligned)
+    if (blockIdx.x == 0 && threadIdx.x == 4) counts[4 * tiles] = 0; // the extra last entry of the scan input
+    const uint64_t tile = (uint64_t)blockIdx.x * IN_WAVES + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
     struct __attribute__((packed, aligned(4))) U4 {
         uint32_t v[4];
     };
-    uint32_t run[4] = {0, 0, 0, 0}; // per lane, summed over the wave once at the end
-    const uint64_t i0 = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
-    if (i0 + IN_ITEMS <= N) {
-        const int64_t p0 = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1); // lowest address of my items
-        uint32_t cw[IN_ITEMS];
+    constexpr int STEPS = IN_TILE / 256; // 256 items per wave step
+    const uint32_t lane = lane_id();
+    const uint64_t t0 = tile * IN_TILE;
+    uint64_t acc = 0;
+    if (t0 + IN_TILE <= N) {
+        U4 t[STEPS];
+        int64_t p0[STEPS];
 #pragma unroll
-        for (int q = 0; q < IN_ITEMS / 4; q++) {
-            const U4 t = *reinterpret_cast<const U4 *>(srcC + p0 + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; e++) cw[4 * q + e] = t.v[e];
+        for (int q = 0; q < STEPS; q++) {
+            const uint64_t i0 = t0 + (uint64_t)q * 256 + 4 * lane;
+            p0[q] = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + 3); // lowest address of my four items
+            t[q] = *reinterpret_cast<const U4 *>(srcC + p0[q]);
         }
 #pragma unroll
-        for (int e = 0; e < IN_ITEMS; e++) {
-            uint32_t c = cw[e];
-            uint32_t cls;
-            if (c == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0 + e, emitmask); // refresh path
-            else {
-                const uint32_t pc = c & 3u;
-                cls = ((emitmask >> pc) & 1u) ? pc : 4u;
-            }
+        for (int q = 0; q < STEPS; q++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) run[k] += cls == (uint32_t)k ? 1u : 0u;
+            for (int e = 0; e < 4; e++) {
+                const uint32_t c = t[q].v[e];
+                uint32_t cls;
+                if (c == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0[q] + e, emitmask); // refresh path
+                else {
+                    const uint32_t pc = c & 3u;
+                    cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+                }
+                acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
+            }
         }
     } else {
-        for (uint64_t i = i0; i < N && i < i0 + IN_ITEMS; i++) {
+        for (uint64_t i = t0 + lane; i < N && i < t0 + IN_TILE; i += 64) {
             const uint32_t cls = item_class_only(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask);
-#pragma unroll
-            for (int k = 0; k < 4; k++) run[k] += cls == (uint32_t)k ? 1u : 0u;
+            acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) run[c] += __shfl_xor(run[c], d, 64);
-    }
-    if (lane_id() == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (run[c]) atomicAdd(&tc[c], run[c]);
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) counts[(uint64_t)threadIdx.x * tiles + blockIdx.x] = tc[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 4) counts[4 * tiles] = 0; // the extra last entry of the scan input
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane < 4) counts[(uint64_t)lane * tiles + tile] = (uint32_t)(acc >> (16 * lane)) & 0xFFFFu;
 }
 
 struct DstPos {
@@ -395,7 +390,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         if (4 * tiles + 1 > ctx->ind_tiles_cap) return KINTERNAL();
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
-            hipLaunchKernelGGL(k_induce_count, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+            hipLaunchKernelGGL(k_induce_count, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
                                srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles);
             KCHECK(hipGetLastError());
         }

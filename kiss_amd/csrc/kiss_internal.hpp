@@ -72,6 +72,7 @@ struct kiss_hip_ctx {
     // one-sweep radix passes (radix.hip): look-back descriptors, digit histograms of all passes, [ticket, error]
     uint64_t *rx_desc = nullptr;
     uint32_t *rx_ghist = nullptr, *rx_ctl = nullptr;
+    uint64_t rx_ghist_count = 0; // != 0: rx_ghist already holds the round-0 digit counts of that many keys (classify.hip)
     uint64_t rx_tiles_cap = 0, rx_epoch = 0;
     uint32_t rx_ticket_base = 0;
     uint64_t *scan_tmp = nullptr;  // block sums for scans
@@ -188,6 +189,9 @@ __device__ __forceinline__ uint32_t kiss_load_ctx(const uint64_t *__restrict__ p
 // unique (82 % on genome-like text) gets its context word without the random text gather of the placement step.
 constexpr uint32_t KISS_KEY_CTX_BASES = 11;
 constexpr uint64_t KISS_KEY_CTX_MASK = 0xFFFFFFull;
+// round 0 of the LMS sort: 20 bases = key bits 24..63 = five 8-bit radix passes
+constexpr int KISS_R0_SHIFT = 24;
+constexpr int KISS_R0_PASSES = 5;
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for this wave's
 // outstanding global stores (vmcnt), so a store burst overlaps the next LDS staging step
 __device__ __forceinline__ void lds_barrier()

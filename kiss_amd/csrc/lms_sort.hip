@@ -828,6 +828,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     rb.seg[0] = rb.seg[1] = nullptr;
     // depth >= 125 whenever bounded, so the first 20 bases always count in full
     const int r0_shift = 64 - 2 * ROUND0_BASES;
+    static_assert(64 - 2 * ROUND0_BASES == KISS_R0_SHIFT && (2 * ROUND0_BASES + 7) / 8 == KISS_R0_PASSES, "classify.hip counts these digits");
     int res = 0;
     KTRY(kiss_radix_sort(ctx, rb, count, r0_shift, 0, &res));
     ctx->stats.lms_rounds++;

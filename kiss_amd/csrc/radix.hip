@@ -10,6 +10,7 @@
 // (reference tie-break `i < j`, include/biovoltron/algo/sort/kiss1_core.hpp:131-133).
 #include "kiss_internal.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -192,6 +193,9 @@ __device__ __forceinline__ void rx_desc_store(uint64_t *p, uint64_t v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef RX_PROF
+__device__ unsigned long long rx_prof[16]; // phase ticks [0..12], look-back hops [13], polls that found nothing [14]
+#endif
 // number of items with digit d in tiles 0 .. tile-1; publishes this tile's count / inclusive prefix
 __device__ __forceinline__ uint32_t rx_lookback(uint64_t *__restrict__ desc, uint32_t tile, uint32_t d, uint32_t tot,
                                                 uint64_t epoch, uint32_t *__restrict__ err)
@@ -203,13 +207,23 @@ __device__ __forceinline__ uint32_t rx_lookback(uint64_t *__restrict__ desc, uin
         return 0;
     }
     rx_desc_store(mine, (1ull << 62) | tag | tot);
+    // The walk is serial on purpose.  Measured with -DRX_PROF: a descriptor load (it has to bypass the per-XCD L2)
+    // takes ~0.55 us and a tile walks ~11 predecessors; the tiles resident at one time move as a convoy (they publish
+    // their counts at about the same time), so a walk that fetches 8 descriptors per round trip sees them all before
+    // any has its prefix, goes three times as far back (32 descriptors) and ends up slower, as did a 16-lane walk.
     uint32_t excl = 0;
     uint32_t t = tile;
+#ifdef RX_PROF
+    uint32_t hops_ = 0, polls_ = 0;
+#endif
     while (t > 0) {
         t--;
         const uint64_t *q = desc + (uint64_t)t * 256 + d;
         uint64_t v = rx_desc_load(q);
         uint32_t spins = 0;
+#ifdef RX_PROF
+        hops_++;
+#endif
         while ((v >> 62) == 0 || (v & (0x3FFFFFFFull << 32)) != tag) {
             if (++spins > RX_SPIN_LIMIT) {
                 *err = 1; // a predecessor never published: give up with what we have (writes stay in range)
@@ -218,10 +232,19 @@ __device__ __forceinline__ uint32_t rx_lookback(uint64_t *__restrict__ desc, uin
             }
             __builtin_amdgcn_s_sleep(1);
             v = rx_desc_load(q);
+#ifdef RX_PROF
+            polls_++;
+#endif
         }
         excl += (uint32_t)v;
         if ((v >> 62) == 2) break;
     }
+#ifdef RX_PROF
+    if (d == 0) {
+        atomicAdd(&rx_prof[13], (unsigned long long)hops_);
+        atomicAdd(&rx_prof[14], (unsigned long long)polls_);
+    }
+#endif
     rx_desc_store(mine, (2ull << 62) | tag | (excl + tot));
     return excl;
 }
@@ -233,6 +256,19 @@ __device__ __forceinline__ uint32_t rx_lookback(uint64_t *__restrict__ desc, uin
 // ONE = false: tile_off holds the scanned per-(tile, digit) offsets (histogram pass + matrix scan ran before);
 // ONE = true : tile_off holds the 256 global digit bases of this pass, tiles are numbered by ticket and find their
 //              offsets by look-back over `desc`
+#ifdef RX_PROF
+#define RX_MARK(i)                                                                                                     \
+    do {                                                                                                               \
+        if (ONE && threadIdx.x == 0) {                                                                                 \
+            const unsigned long long now_ = wall_clock64();                                                            \
+            atomicAdd(&rx_prof[i], now_ - t_prev_);                                                                    \
+            t_prev_ = now_;                                                                                            \
+        }                                                                                                              \
+    } while (0)
+#else
+#define RX_MARK(i)
+#endif
+
 template <int SRC, bool HAS_SEG, bool ONE>
 __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t *__restrict__ key_in,
                                                                 const uint32_t *__restrict__ seg_in,
@@ -255,10 +291,14 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
 
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
+#ifdef RX_PROF
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     if (ONE) {
         if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[0], 1u) - ticket_base;
         __syncthreads();
     }
+    RX_MARK(0);
     const uint32_t tile = ONE ? s_tile : blockIdx.x;
     const uint64_t tile_base = (uint64_t)tile * RX_TILE;
     const uint32_t tile_count = (uint32_t)((count - tile_base) < (uint64_t)RX_TILE ? (count - tile_base) : RX_TILE);
@@ -275,41 +315,66 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     uint32_t rk[RX_ITEMS]; // (digit << 16) | rank inside the wave among equal digits; 0xFFFFFFFF = invalid
 
     const uint32_t wbase = (uint32_t)wave * RX_WAVE_TILE + lane;
+    if (tile_count == RX_TILE) { // full tile: no per-item bounds checks around the loads
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const uint32_t li = wbase + (uint32_t)j * 64;
-        const bool valid = li < tile_count;
-        const uint64_t g = tile_base + li;
-        k[j] = valid ? key_in[g] : 0ull;
-        s[j] = (HAS_SEG && valid) ? seg_in[g] : 0u;
-        p[j] = valid ? pos_in[g] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const uint32_t li = wbase + (uint32_t)j * 64;
-        const bool valid = li < tile_count;
-        const uint32_t d = digit_of<SRC>(k[j], s[j], shift);
-        // lanes holding the same digit: AND over the 8 digit bits of (bit ? ballot : ~ballot) = ~(ballot ^ -bit)
-        const uint64_t vm = __ballot(valid);
-        uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint32_t sel = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1); // 0 or ~0: one v_bfe_i32
-            const uint64_t bm = __ballot(sel != 0u);
-            plo &= ~((uint32_t)bm ^ sel);
-            phi &= ~((uint32_t)(bm >> 32) ^ sel);
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const uint64_t g = tile_base + wbase + (uint32_t)j * 64;
+            k[j] = key_in[g];
+            s[j] = HAS_SEG ? seg_in[g] : 0u;
+            p[j] = pos_in[g];
         }
-        const uint64_t peers = ((uint64_t)phi << 32) | plo;
-        uint32_t old = 0;
-        int leader = 0;
-        if (valid) {
-            leader = __ffsll((unsigned long long)peers) - 1;
-            if ((int)lane == leader) old = atomicAdd(&wcnt[wave][d], (uint32_t)__popcll(peers));
+    } else {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const uint32_t li = wbase + (uint32_t)j * 64;
+            const bool valid = li < tile_count;
+            const uint64_t g = tile_base + li;
+            k[j] = valid ? key_in[g] : 0ull;
+            s[j] = (HAS_SEG && valid) ? seg_in[g] : 0u;
+            p[j] = valid ? pos_in[g] : 0u;
         }
-        old = __shfl(old, leader, 64);
-        rk[j] = valid ? ((d << 16) | (old + (uint32_t)__popcll(peers & lanemask_lt()))) : 0xFFFFFFFFu;
     }
+#ifdef RX_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RX_MARK(1);
+#endif
+    // Rank inside the wave: lanes holding the same digit = AND over the 8 digit bits of (bit ? ballot : ~ballot); with
+    // sel = 0 / ~0 that is one three-input boolean op per half and bit (v_bitop3: acc & ~(ballot ^ sel)).  The rank
+    // phase is VALU-bound (phase profile), so the loop is written instruction by instruction: the
+    // running count of the digit is READ by all its lanes (one broadcast) and written back by the lowest one, instead
+    // of an atomic with return in a leader plus a cross-lane broadcast.
+    uint32_t *const wc = wcnt[wave];
+    auto rank_items = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const bool valid = FULL || wbase + (uint32_t)j * 64 < tile_count;
+            const uint32_t d = digit_of<SRC>(k[j], s[j], shift);
+            uint32_t plo = ~0u, phi = ~0u;
+            if (!FULL) {
+                const uint64_t vm = __ballot(valid);
+                plo = (uint32_t)vm;
+                phi = (uint32_t)(vm >> 32);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int sel = __builtin_amdgcn_sbfe((int)d, b, 1); // 0 or ~0
+                const uint64_t bm = __ballot(sel < 0);
+                plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bm, (uint32_t)sel, 0x90);
+                phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bm >> 32), (uint32_t)sel, 0x90);
+            }
+            // equal digits in lower lanes; the lowest lane of the group moves the running count on
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t old = wc[d];
+            if (below == 0 && valid) wc[d] = old + (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+            rk[j] = valid ? ((d << 16) | (old + below)) : 0xFFFFFFFFu;
+        }
+    };
+    if (tile_count == RX_TILE) rank_items(std::true_type{});
+    else rank_items(std::false_type{});
+    RX_MARK(2);
     __syncthreads();
+    RX_MARK(3);
 
     // per digit (threads 0..255): totals over waves, exclusive prefix over waves, exclusive scan over digits
     {
@@ -330,11 +395,10 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
         }
         if (lane == 63 && dig) wsum[wave] = inc;
         __syncthreads();
+        RX_MARK(4);
+        uint32_t start = inc - tot;
         if (dig) {
-            uint32_t start = inc - tot;
             for (int w = 0; w < wave; w++) start += wsum[w];
-            if (ONE) gbase[d] = tile_off[d] + rx_lookback(desc, tile, d, tot, epoch, &ctl[1]) - start;
-            else gbase[d] = tile_off[(uint64_t)tile * 256 + d] - start;
             uint32_t run = start;
 #pragma unroll
             for (int w = 0; w < RX_WAVES; w++) {
@@ -342,14 +406,19 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
                 run += c[w];
             }
         }
+        __syncthreads(); // local offsets are known: the other waves stage their items while waves 0..3 look back
+        RX_MARK(5);
+        if (dig) {
+            if (ONE) gbase[d] = tile_off[d] + rx_lookback(desc, tile, d, tot, epoch, &ctl[1]) - start;
+            else gbase[d] = tile_off[(uint64_t)tile * 256 + d] - start;
+        }
     }
-    __syncthreads();
+    RX_MARK(6);
 
     // local positions of this thread's items
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++)
         if (rk[j] != 0xFFFFFFFFu) rk[j] = wcnt[wave][rk[j] >> 16] + (rk[j] & 0xFFFFu);
-
     // global offsets of the output slots this thread will write: slot idx = threadIdx.x + 256 * r
     uint32_t gofs[RX_ITEMS];
 
@@ -359,6 +428,7 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
         for (int j = 0; j < RX_ITEMS; j++)
             if (rk[j] != 0xFFFFFFFFu) stage64[rk[j]] = k[j];
         lds_barrier();
+        RX_MARK(7);
 #pragma unroll
         for (int r = 0; r < RX_ITEMS; r++) {
             const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
@@ -368,7 +438,9 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
                 key_out[gofs[r]] = kk;
             }
         }
+        RX_MARK(8);
         lds_barrier();
+        RX_MARK(9);
         if (HAS_SEG) {
 #pragma unroll
             for (int j = 0; j < RX_ITEMS; j++)
@@ -412,11 +484,16 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     for (int j = 0; j < RX_ITEMS; j++)
         if (rk[j] != 0xFFFFFFFFu) stage32[rk[j]] = p[j];
     lds_barrier();
+    RX_MARK(10);
 #pragma unroll
     for (int r = 0; r < RX_ITEMS; r++) {
         const uint32_t idx = threadIdx.x + (uint32_t)r * RX_THREADS;
         if (idx < tile_count) pos_out[gofs[r]] = stage32[idx];
     }
+#ifdef RX_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RX_MARK(11);
+#endif
 }
 
 // ---- digit-major exclusive scan of the tile-major histogram matrix hist[tile][256] ------------------
@@ -534,6 +611,19 @@ int radix_pass_one(kiss_hip_ctx *ctx, RadixBufs &b, int src, uint64_t count, int
 int kiss_radix_check(kiss_hip_ctx *ctx)
 {
     if (!ctx->rx_ctl) return KISS_HIP_OK;
+#ifdef RX_PROF
+    {
+        unsigned long long h[16], z[16] = {0};
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        KCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(rx_prof), sizeof h));
+        KCHECK(hipMemcpyToSymbol(HIP_SYMBOL(rx_prof), z, sizeof z));
+        unsigned long long tot = 0;
+        for (int i = 0; i < 13; i++) tot += h[i];
+        fprintf(stderr, "[rx_prof] phase ticks (thread 0 of every tile), total %llu:", tot);
+        for (int i = 0; i < 13; i++) fprintf(stderr, " %d:%.1f%%", i, tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
+        fprintf(stderr, "  | look-back of digit 0: %llu hops, %llu empty polls\n", h[13], h[14]);
+    }
+#endif
     uint32_t err = 0;
     KCHECK(hipMemcpyAsync(&err, ctx->rx_ctl + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
@@ -554,7 +644,14 @@ int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_
         const uint64_t tiles = div_up(count, RX_TILE);
         static const bool no_one = getenv("KISS_HIP_NO_ONESWEEP") != nullptr; // measurement hook
         const bool one = !no_one && ctx->rx_desc && tiles >= 2 && tiles <= ctx->rx_tiles_cap && n_key + n_seg <= RX_MAX_PASSES;
-        if (one) {
+        // digit counts that came with the keys (classify.hip, round 0 only)
+        const bool counted = one && ctx->rx_ghist_count == count && !has_seg && shift0 == KISS_R0_SHIFT && b.first_pos;
+        ctx->rx_ghist_count = 0;
+        if (counted) {
+            KTimer t(ctx, KISS_HIP_K_RADIX_HIST, 0);
+            hipLaunchKernelGGL(k_radix_digit_bases, dim3((unsigned)n_key), dim3(256), 0, ctx->stream, ctx->rx_ghist);
+            KCHECK(hipGetLastError());
+        } else if (one) {
             KTimer t(ctx, KISS_HIP_K_RADIX_HIST, count);
             KTRY(kiss_zero_u32(ctx, ctx->rx_ghist, 256ull * (uint64_t)(n_key + n_seg)));
             const uint32_t per = 256u * (uint32_t)(n_key + n_seg);

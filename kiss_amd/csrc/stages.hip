@@ -148,6 +148,7 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
         KCHECK(hipMemcpyAsync(ctx->lms_pos, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     ctx->m = ctx->m_far = count;
+    ctx->rx_ghist_count = 0; // these keys did not come from this context's emit pass
     KTRY(kiss_lms_sort(ctx, n, k, depth_of(n, k)));
     if (count) {
         KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
