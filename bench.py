@@ -3,8 +3,11 @@
 
 A "step" is one pass of the hot path (pack -> get_lms -> k-ordered LMS sort -> induction) over one
 synthetic chm13-sized text (n = 3 117 292 070, k = 256) that is already resident in HBM when the
-timed region starts; the SA stays in HBM.  One process per GPU.  For N > 1 each rank sorts its own
-text of the same size (independent objects, no data-path collective): weak scaling.
+timed region starts; the SA stays in HBM.  One process per GPU.  For N > 1 the default (--mode sharded) sorts ONE
+text: the LMS sort is sharded by key range over the ranks (RCCL all-to-all of the LMS list, gather of the sorted
+pieces, induction on rank 0) -> "scaling": "strong"; --mode replicas sorts one independent text per rank (no
+data-path collective) -> "scaling": "weak".  If the sharded exchange fails, the run falls back to replicas and says so
+(config.sharded_error).
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
