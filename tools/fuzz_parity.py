@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Differential fuzzing on the GPU box: random (text shape, n, k, algorithm) cases, library vs CPU oracle, bit for bit.
+Usage: fuzz_parity.py [seconds] [seed].  Prints one line per failure and a summary; exit code 1 on any mismatch."""
+import os
+import sys
+import time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kiss_amd
+from tests import gen, oracle_binding
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+orc = oracle_binding.load()
+ctx = kiss_amd.Context(max_n=4_000_000)
+t0 = time.time()
+cases = fails = 0
+kinds = ["iid", "periodic", "genome", "runs", "two_letter", "blocks", "near_end_repeat"]
+while time.time() - t0 < budget:
+    kind = kinds[int(rng.integers(0, len(kinds)))]
+    kk = [1, 2, 31, 32, 33, 124, 125, 126, 249, 250, 256, 375, 400, 1000, 0xFFFFFFFF, 0xFFFFFFFF]
+    k = int(kk[int(rng.integers(0, len(kk)))])
+    # the oracle's exact comparator is quadratic on long repeats: keep those cases small
+    nmax = 30_000 if (k == 0xFFFFFFFF and kind not in ("iid", "genome")) else 3_000_000
+    n = int(np.exp(rng.uniform(np.log(1), np.log(nmax))))
+    s = int(rng.integers(0, 1 << 30))
+    if kind == "iid":
+        S = gen.iid(n, s)
+    elif kind == "periodic":
+        S = gen.periodic(n, int(rng.integers(1, 500)), s, int(rng.integers(0, 40)))
+    elif kind == "genome":
+        S = gen.genome_like(n, s)
+    elif kind == "runs":  # long runs of single bases with random lengths
+        lens = np.maximum(1, (rng.pareto(1.2, max(1, n // 20)) * 5).astype(np.int64))
+        S = np.repeat(rng.integers(0, 4, lens.size, dtype=np.uint8), lens)[:n]
+        if S.size < n:
+            S = np.concatenate([S, gen.iid(n - S.size, s)])
+    elif kind == "two_letter":
+        S = (rng.integers(0, 2, n, dtype=np.uint8) * int(rng.integers(1, 4))).astype(np.uint8)
+    elif kind == "blocks":  # copies of one random block, a few point mutations
+        b = gen.iid(int(rng.integers(1, max(2, n // 3 + 1))), s)
+        S = np.tile(b, n // b.size + 1)[:n].copy()
+        if n > 10:
+            idx = rng.integers(0, n, int(rng.integers(0, 6)))
+            S[idx] = rng.integers(0, 4, idx.size, dtype=np.uint8)
+    else:  # the text ends inside a repeat (end-of-text rule of the comparator)
+        u = gen.iid(int(rng.integers(1, 60)), s)
+        tail = np.tile(u, int(rng.integers(1, 40)))
+        S = np.concatenate([gen.iid(max(0, n - tail.size), s + 1), tail])[:n]
+    S = np.ascontiguousarray(S, dtype=np.uint8)
+    n = int(S.size)
+    algo = int(rng.integers(0, 2)) if k == 0xFFFFFFFF else 0
+    try:
+        sa = ctx.suffix_sort(S, k, algo=algo)
+    except Exception as e:  # noqa: BLE001
+        if "UNSUPPORTED" in str(e).upper() or "unsupported" in str(e):
+            continue
+        print("ERROR kind=%s n=%d k=%d algo=%d seed=%d: %s" % (kind, n, k, algo, s, e), flush=True)
+        fails += 1
+        continue
+    ref = orc.suffix_sort(S, k)
+    cases += 1
+    if not np.array_equal(np.asarray(sa).view(np.uint32), ref):
+        fails += 1
+        print("MISMATCH kind=%s n=%d k=%d algo=%d seed=%d" % (kind, n, k, algo, s), flush=True)
+print("fuzz: %d cases, %d failures, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed), flush=True)
+sys.exit(1 if fails else 0)
