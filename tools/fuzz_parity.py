@@ -13,7 +13,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 orc = oracle_binding.load()
-ctx = kiss_amd.Context(max_n=4_000_000)
+NMAX = int(os.environ.get("FUZZ_NMAX", "3000000"))  # bounded-k and iid / genome cases go up to this size
+ctx = kiss_amd.Context(max_n=NMAX + 1_000_000)
 t0 = time.time()
 cases = fails = 0
 kinds = ["iid", "periodic", "genome", "runs", "two_letter", "blocks", "near_end_repeat"]
@@ -22,7 +23,7 @@ while time.time() - t0 < budget:
     kk = [1, 2, 31, 32, 33, 124, 125, 126, 249, 250, 256, 375, 400, 1000, 0xFFFFFFFF, 0xFFFFFFFF]
     k = int(kk[int(rng.integers(0, len(kk)))])
     # the oracle's exact comparator is quadratic on long repeats: keep those cases small
-    nmax = 30_000 if (k == 0xFFFFFFFF and kind not in ("iid", "genome")) else 3_000_000
+    nmax = 30_000 if (k == 0xFFFFFFFF and kind not in ("iid", "genome")) else NMAX
     n = int(np.exp(rng.uniform(np.log(1), np.log(nmax))))
     s = int(rng.integers(0, 1 << 30))
     if kind == "iid":
