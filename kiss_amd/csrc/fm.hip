@@ -87,7 +87,8 @@ __device__ __forceinline__ uint32_t fm_b_occ(const FmiD &f, uint64_t i)
 // ---- backward search: one lane per pattern -------------------------------------------------------
 __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *__restrict__ pat, uint32_t L, uint64_t Q,
                                                         uint32_t *__restrict__ beg_out, uint32_t *__restrict__ end_out,
-                                                        uint64_t *__restrict__ cap /* hits + 4 per pattern */,
+                                                        uint64_t *__restrict__ cap /* offset slots per pattern */,
+                                                        uint64_t *__restrict__ fcap /* frontier slots per pattern */,
                                                         uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ nheavy)
 {
     uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
@@ -106,7 +107,12 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
     }
     beg_out[q] = (uint32_t)beg;
     end_out[q] = (uint32_t)end;
-    cap[q] = (end - beg) + 4;
+    // get_offsets (fm_index.hpp:472-482) tests `offsets.size() < end - beg` only BEFORE a range is taken from the queue
+    // and then emits every sampled row of that range: on an index whose k-ordered SA ties long repeats (telomere-like
+    // arrays under the k = 32 build) the walk returns MORE than end - beg positions.  Fewer than end - beg were out
+    // before the last range and a range never holds more rows than the first one: at most 2 (end - beg) - 1 positions.
+    cap[q] = 2 * (end - beg) + 4;
+    fcap[q] = end - beg > FM_HEAVY ? 0 : (end - beg) + 4; // ranges of one level (rows of a level <= end - beg)
     if (end - beg > FM_HEAVY) heavy_list[atomicAdd(nheavy, 1u)] = (uint32_t)q; // located by a workgroup (order irrelevant)
 }
 
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
 __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t *__restrict__ beg_in,
                                                          const uint32_t *__restrict__ end_in, uint64_t Q,
                                                          const uint64_t *__restrict__ cap_index,
+                                                         const uint64_t *__restrict__ fcap_index,
                                                          uint2 *__restrict__ frontier0, uint2 *__restrict__ frontier1,
                                                          uint32_t *__restrict__ out, uint64_t *__restrict__ got_out,
                                                          unsigned long long *__restrict__ totals)
@@ -123,11 +130,11 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
     if (q < Q) {
         const uint64_t b0 = beg_in[q], e0 = end_in[q];
         const uint64_t want = e0 - b0 > FM_HEAVY ? 0 : e0 - b0; // heavy patterns: k_fm_locate_heavy
-        const uint64_t base = cap_index[q];
-        const uint64_t capq = want + 4;
-        uint2 *cur = frontier0 + base, *nxt = frontier1 + base;
+        const uint64_t base = cap_index[q], fbase = fcap_index[q];
+        const uint64_t capq = 2 * want + 4, fcapq = want + 4;
+        uint2 *cur = frontier0 + fbase, *nxt = frontier1 + fbase;
         uint64_t ncur = 1;
-        cur[0] = make_uint2((uint32_t)b0, (uint32_t)e0);
+        if (e0 - b0 <= FM_HEAVY) cur[0] = make_uint2((uint32_t)b0, (uint32_t)e0); // (a heavy pattern owns no frontier slots)
         bool stop = false;
         for (int dep = 0; dep < 4 && !stop; dep++) {
             uint64_t nn = 0;
@@ -148,14 +155,14 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
                 if (dep + 1 == 4) continue;
                 if (cb + 1 == ce) {
                     uint64_t nb = fm_lf(f, fm_bwt(f, cb), cb);
-                    if (nn < capq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
+                    if (nn < fcapq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
                     nn++;
                 } else {
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++) {
                         uint64_t nb = fm_lf(f, c, cb), ne = fm_lf(f, c, ce);
                         if (nb != ne) {
-                            if (nn < capq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)ne);
+                            if (nn < fcapq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)ne);
                             nn++;
                         }
                     }
@@ -164,10 +171,10 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
             uint2 *tmp = cur;
             cur = nxt;
             nxt = tmp;
-            ncur = nn < capq ? nn : capq;
+            ncur = nn < fcapq ? nn : fcapq;
         }
         if (e0 - b0 <= FM_HEAVY) got_out[q] = got < capq ? got : capq;
-        if (got > capq) got = capq; // can not happen; keeps totals consistent with the buffers
+        if (got > capq) got = capq; // can not happen (bound above); keeps totals consistent with the buffers
     }
     // wave-level reduction of (hits, checksum), one atomic pair per wave
     unsigned long long g = got, s = sum;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const u
     __shared__ unsigned long long s_sum[FMH_THREADS / 64];
     const uint32_t q = heavy_list[blockIdx.x];
     const uint64_t b0 = beg_in[q], e0 = end_in[q];
-    const uint64_t want = e0 - b0, base = cap_index[q], capq = want + 4;
+    const uint64_t want = e0 - b0, base = cap_index[q], capq = 2 * want + 4;
     if (threadIdx.x == 0) {
         fr[0][0] = make_uint2((uint32_t)b0, (uint32_t)e0);
         s_n = 1;
@@ -491,11 +498,13 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     f.b = fmi->b;
     f.b_occ = fmi->b_occ;
 
-    DevBuf cap, capidx, got, gotidx, tot, fr0, fr1, scratch, heavy;
+    DevBuf cap, capidx, fcap, fcapidx, got, gotidx, tot, fr0, fr1, scratch, heavy;
     KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
     KTRY(cap.take(ctx, 1, (Q + 1) * 8));
     KTRY(capidx.take(ctx, 2, (Q + 1) * 8));
+    KTRY(fcap.take(ctx, 9, (Q + 1) * 8));
+    KTRY(fcapidx.take(ctx, 10, (Q + 1) * 8));
     KTRY(got.take(ctx, 3, (Q + 1) * 8));
     KTRY(gotidx.take(ctx, 4, (Q + 1) * 8));
     KTRY(tot.take(ctx, 5, 16));
@@ -503,24 +512,28 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
         hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
-                           (uint64_t *)cap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p);
+                           (uint64_t *)cap.p, (uint64_t *)fcap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p);
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_zero_u32(ctx, (uint8_t *)cap.p + Q * 8, 2));
     KTRY(kiss_scan_u64(ctx, (const uint64_t *)cap.p, (uint64_t *)capidx.p, Q + 1));
-    uint64_t total_cap = 0;
+    KTRY(kiss_zero_u32(ctx, (uint8_t *)fcap.p + Q * 8, 2));
+    KTRY(kiss_scan_u64(ctx, (const uint64_t *)fcap.p, (uint64_t *)fcapidx.p, Q + 1));
+    uint64_t total_cap = 0, total_fcap = 0;
     uint32_t nheavy = 0;
     KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipMemcpyAsync(&total_fcap, (uint8_t *)fcapidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipMemcpyAsync(&nheavy, heavy.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
-    KTRY(fr0.take(ctx, 6, total_cap * sizeof(uint2)));
-    KTRY(fr1.take(ctx, 7, total_cap * sizeof(uint2)));
+    KTRY(fr0.take(ctx, 6, (total_fcap + 1) * sizeof(uint2)));
+    KTRY(fr1.take(ctx, 7, (total_fcap + 1) * sizeof(uint2)));
     KTRY(scratch.take(ctx, 8, total_cap * sizeof(uint32_t)));
     KTRY(kiss_zero_u32(ctx, tot.p, 4));
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
         hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
-                           (const uint64_t *)capidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p, (uint32_t *)scratch.p,
+                           (const uint64_t *)capidx.p, (const uint64_t *)fcapidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p,
+                           (uint32_t *)scratch.p,
                            (uint64_t *)got.p, (unsigned long long *)tot.p);
         if (nheavy)
             hipLaunchKernelGGL(k_fm_locate_heavy, dim3(nheavy), dim3(FMH_THREADS), 0, ctx->stream, f, beg, end,

@@ -87,8 +87,8 @@ struct kiss_hip_ctx {
     uint64_t *pairs1 = nullptr, *pairs2 = nullptr;
     uint64_t pairs_cap = 0;
     // scratch of kiss_hip_fmi_query_batch_dev, kept between calls (fm.hip)
-    void *fm_pool[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint64_t fm_pool_cap[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void *fm_pool[11] = {};
+    uint64_t fm_pool_cap[11] = {};
     // near-end
     uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr;
     uint64_t near_cap = 0;

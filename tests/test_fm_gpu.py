@@ -86,3 +86,29 @@ def test_heavy_patterns_keep_the_fifo_order(oracle, L):
     assert np.array_equal(a["offsets_index"], b["offsets_index"])
     assert np.array_equal(a["offsets"], b["offsets"])
     f.close()
+
+
+@pytest.mark.parametrize("tail", [3000, 700])
+def test_locate_returns_more_than_the_range_on_tied_repeats(oracle, tail):
+    """get_offsets (fm_index.hpp:472-482) checks `offsets.size() < end - beg` only before it takes a range from the queue:
+    on the k = 32 index of a text with a long tandem array (ties past the comparison depth) the walk returns MORE
+    positions than end - beg.  The library must return the same list (found by tools/fuzz_fm.py: a text that is mostly
+    (TTAGGG)n; the old per-pattern capacity of end - beg + 4 cut one position off)."""
+    import kiss_amd.fm_index as fm
+    rng = np.random.default_rng(3)
+    unit = np.array([3, 3, 0, 2, 2, 2], dtype=np.uint8)
+    S = np.concatenate([gen.iid(500, 1), np.tile(unit, tail // 6), gen.iid(300, 2), np.tile(unit, tail // 6),
+                        gen.iid(40, 4)]).astype(np.uint8)
+    f = fm.FMIndex().build(S)
+    ref = oracle.fm_build(S, oracle.suffix_sort(S, 32))
+    pats = []
+    for L in (6, 20, 38):
+        for sh in range(6):
+            pats.append(np.tile(unit, 10)[sh:sh + L])
+        a = f.query_batch(np.stack(pats[-6:]), want_offsets=True)
+        b = ref.query_batch(np.stack(pats[-6:]), want_offsets=True)
+        assert a["total_hits"] == b["total_hits"] and a["checksum"] == b["checksum"]
+        assert np.array_equal(a["beg"], b["beg"]) and np.array_equal(a["end"], b["end"])
+        assert np.array_equal(a["offsets_index"], b["offsets_index"]) and np.array_equal(a["offsets"], b["offsets"])
+    del rng
+    f.close()
