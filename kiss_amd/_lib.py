@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libkiss_hip.so")
 
 KISS_HIP_OK = 0
 KISS_HIP_E_INVALID, KISS_HIP_E_NO_DEVICE, KISS_HIP_E_HIP, KISS_HIP_E_NOMEM = -1, -2, -3, -4
-KISS_HIP_E_UNSUPPORTED, KISS_HIP_E_INTERNAL, KISS_HIP_E_IO = -5, -6, -7
+KISS_HIP_E_UNSUPPORTED, KISS_HIP_E_INTERNAL, KISS_HIP_E_IO, KISS_HIP_E_DEEP = -5, -6, -7, -8
 ALGO_PARALLEL_SORTING = 0
 ALGO_PREFIX_DOUBLING = 1
 MAX_N = 4294967276
@@ -100,6 +100,8 @@ def load():
     lib.kiss_hip_stage_partition.argtypes = [vp, vp, vp, u64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
     lib.kiss_hip_stage_sort.argtypes = [vp, vp, vp, u64, u64, ctypes.c_uint32, vp, vp, vp]
     lib.kiss_hip_stage_induce.argtypes = [vp, u64, ctypes.c_uint32, vp, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp]
+    lib.kiss_hip_stage_refine_exact.argtypes = [vp, u64, ctypes.c_uint32, vp, vp]
+    lib.kiss_hip_stage_refine_exact.restype = ctypes.c_int
     lib.kiss_hip_fmi_query_batch_dev.argtypes = [
         vp, ctypes.POINTER(FmiView), vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp,
         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), vp, vp, ctypes.c_uint64, vp]
@@ -144,7 +146,7 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_ctx_get_stage_outputs", "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
     "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
     "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
-    "kiss_hip_stage_sort", "kiss_hip_stage_induce",
+    "kiss_hip_stage_sort", "kiss_hip_stage_induce", "kiss_hip_stage_refine_exact",
     "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
     "kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file", "kiss_hip_copy_to_host",
     "kiss_hip_free_dev", "kiss_hip_alloc_dev", "kiss_hip_suffix_sort_u8", "kiss_hip_ctx_suffix_sort_u8_dev",

@@ -307,6 +307,7 @@ const char *kiss_hip_strerror(int status)
     case KISS_HIP_E_UNSUPPORTED: return "request outside the implemented range";
     case KISS_HIP_E_INTERNAL: return "internal invariant violated";
     case KISS_HIP_E_IO: return "file could not be opened or read";
+    case KISS_HIP_E_DEEP: return "ties deeper than the bounded-round exact path handles: use k = 256 + stage_refine_exact";
     default: return "unknown status";
     }
 }

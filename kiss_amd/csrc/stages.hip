@@ -149,7 +149,14 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     }
     ctx->m = ctx->m_far = count;
     ctx->rx_ghist_count = 0; // these keys did not come from this context's emit pass
-    KTRY(kiss_lms_sort(ctx, n, k, depth_of(n, k)));
+    {
+        const int rc = kiss_lms_sort(ctx, n, k, depth_of(n, k));
+        if (rc == KISS_INTERNAL_TOO_DEEP) { // exact order on very long repeats: the caller switches to k = 256 + doubling
+            (void)hipStreamSynchronize(ctx->stream);
+            return KISS_HIP_E_DEEP;
+        }
+        if (rc) return rc;
+    }
     if (count) {
         KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_ctx_out) // context words from the key payload (0 = to be gathered), parallel to the sorted positions
@@ -192,3 +199,16 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
 }
 
 } // extern "C"
+
+int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, void *stream)
+{
+    if (!ctx || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID; // stage_classify packed the text of this ctx
+    if (h0 < 32 || n < 4ull * h0 + 1024) return KISS_HIP_E_UNSUPPORTED;
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_exact_refine(ctx, n, h0, d_SA));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_radix_check(ctx));
+    ktimer_collect(ctx);
+    return KISS_HIP_OK;
+}

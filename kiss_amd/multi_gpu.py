@@ -21,6 +21,7 @@ from . import _lib
 from .sorter import _check
 
 HIST_BITS = 16
+EXACT_H0 = 256  # bounded order of the first phase when exact order falls back to rank doubling
 
 
 class GpuBackend:
@@ -80,15 +81,25 @@ class GpuBackend:
         return ko, po
 
     def sort(self, keys, pos):
-        """-> (k-ordered positions, their context words from the key payload; 0 = to be gathered)"""
+        """-> (k-ordered positions, their context words from the key payload; 0 = to be gathered), or None when exact
+        order was asked for and the ties are deeper than the 32-bases-per-round path handles (KISS_HIP_E_DEEP)"""
         self._sync()
         out = self.torch.empty_like(pos)
         cw = self.torch.empty_like(pos)
-        _check(self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
-                                            int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()),
-                                            ctypes.c_void_p(cw.data_ptr()), None),
-               "kiss_hip_stage_sort", self.ctx._ctx)
+        rc = self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
+                                          int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()),
+                                          ctypes.c_void_p(cw.data_ptr()), None)
+        if rc == _lib.KISS_HIP_E_DEEP:
+            return None
+        _check(rc, "kiss_hip_stage_sort", self.ctx._ctx)
         return out, cw
+
+    def refine_exact(self, SA, h0):
+        """h0-ordered SA -> exact SA by rank doubling (rank 0, after a pipeline run with k = h0)"""
+        self._sync()
+        _check(self.lib.kiss_hip_stage_refine_exact(self.ctx._ctx, self.n, int(h0), ctypes.c_void_p(SA.data_ptr()), None),
+               "kiss_hip_stage_refine_exact", self.ctx._ctx)
+        return SA
 
     def induce(self, far_all, near_all, counts12, SA=None, far_ctx=None):
         self._sync()
@@ -303,7 +314,28 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     rpos = backend.empty(R, torch.int32)
     comm.all_to_all(rkeys, skeys, recv_counts, send_counts)
     comm.all_to_all(rpos, spos, recv_counts, send_counts)
-    sorted_piece, piece_ctx = backend.sort(rkeys, rpos)
+    res = backend.sort(rkeys, rpos)
+    if int(backend.k) >= n:
+        # exact order: a rank whose key range holds ties deeper than the bounded-round path handles (tandem arrays of
+        # tens of kilobases) reports it; then every rank runs the pipeline again for k = 256 and rank 0 finishes with
+        # rank doubling over the whole SA -- what the single-GPU entry point does by itself (api.hip)
+        deep = sum(comm.all_gather_ints(1 if res is None else 0))
+        if deep:
+            if n < 4 * EXACT_H0 + 1024:
+                raise RuntimeError("sharded exact sort: ties too deep on a text too short for the doubling form")
+            k_exact = backend.k
+            backend.k = EXACT_H0
+            try:
+                out = sharded_suffix_sort(backend, n, group=group, SA=SA, timings=timings)
+            finally:
+                backend.k = k_exact
+            if r == 0:
+                out = backend.refine_exact(out, EXACT_H0)
+            comm.barrier()
+            return out
+    elif res is None:
+        raise RuntimeError("kiss_hip_stage_sort: unexpected KISS_HIP_E_DEEP for a bounded k")
+    sorted_piece, piece_ctx = res
     piece_counts = comm.all_gather_ints(R)
     far_all = comm.gather_to_root(sorted_piece, piece_counts, backend.empty)
     # the context words travel with the pieces (4 more bytes per LMS suffix over xGMI instead of a random text

@@ -171,7 +171,9 @@ def _gpu_worker(rank, world, port, n, k, seed, q):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2, 3])
-@pytest.mark.parametrize("n,k", [(300_000, 256), (1_000_000, 32), (200_000, 0xFFFFFFFF)])
+# (65541, exact): a text that is one long (TTAGGG)n array -- ties deeper than the bounded-round exact path handles, so the
+# ranks agree to run k = 256 and rank 0 finishes by rank doubling (found by tools/fuzz_sharded.py)
+@pytest.mark.parametrize("n,k", [(300_000, 256), (1_000_000, 32), (200_000, 0xFFFFFFFF), (65_541, 0xFFFFFFFF)])
 def test_sharded_pipeline_real_kernels(world, n, k):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
