@@ -9,6 +9,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kiss_amd
 from tests import gen, oracle_binding
 
+def sa_is_exact(S, sa):
+    """linear-time suffix array check: a permutation, and (S[a], rank[a+1]) strictly increasing along SA"""
+    n = S.size
+    if sa.size != n + 1 or sa[0] != n:
+        return False
+    isa = np.full(n + 2, -1, np.int64)
+    isa[sa] = np.arange(n + 1)
+    if (isa[:n + 1] < 0).any():
+        return False
+    a, b = sa[1:-1].astype(np.int64), sa[2:].astype(np.int64)
+    ka = S[a].astype(np.int64) * (n + 2) + isa[a + 1]
+    kb = S[b].astype(np.int64) * (n + 2) + isa[b + 1]
+    return bool((ka < kb).all())
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -22,8 +37,10 @@ while time.time() - t0 < budget:
     kind = kinds[int(rng.integers(0, len(kinds)))]
     kk = [1, 2, 31, 32, 33, 124, 125, 126, 249, 250, 256, 375, 400, 1000, 0xFFFFFFFF, 0xFFFFFFFF]
     k = int(kk[int(rng.integers(0, len(kk)))])
-    # the oracle's exact comparator is quadratic on long repeats: keep those cases small
-    nmax = 30_000 if (k == 0xFFFFFFFF and kind not in ("iid", "genome")) else NMAX
+    # the oracle's exact comparator is quadratic on long repeats: those cases are checked with the linear-time
+    # suffix-array test instead (the exact suffix array is unique, so the test is a complete oracle)
+    linear = k == 0xFFFFFFFF and kind not in ("iid", "genome")
+    nmax = NMAX
     n = int(np.exp(rng.uniform(np.log(1), np.log(nmax))))
     s = int(rng.integers(0, 1 << 30))
     if kind == "iid":
@@ -60,9 +77,12 @@ while time.time() - t0 < budget:
         print("ERROR kind=%s n=%d k=%d algo=%d seed=%d: %s" % (kind, n, k, algo, s, e), flush=True)
         fails += 1
         continue
-    ref = orc.suffix_sort(S, k)
     cases += 1
-    if not np.array_equal(np.asarray(sa).view(np.uint32), ref):
+    if linear and n > 30_000:
+        good = sa_is_exact(S, np.asarray(sa).view(np.uint32))
+    else:
+        good = np.array_equal(np.asarray(sa).view(np.uint32), orc.suffix_sort(S, k))
+    if not good:
         fails += 1
         print("MISMATCH kind=%s n=%d k=%d algo=%d seed=%d" % (kind, n, k, algo, s), flush=True)
 print("fuzz: %d cases, %d failures, %.0f s, seed %d" % (cases, fails, time.time() - t0, seed), flush=True)
