@@ -38,7 +38,7 @@ while time.time() - t0 < budget:
     if not ok:
         print("  .fmi bytes differ", flush=True)
     for _ in range(200 if replay else 3):
-        L = int(rng.integers(1, 41))
+        L = int(rng.integers(1, int(os.environ.get("FUZZ_LMAX", "40")) + 1))
         if L >= n:
             continue
         Q = int(rng.integers(1, 3000))
