@@ -122,7 +122,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           uint64_t off, uint64_t depth, uint32_t small_seg,
                                                           const uint8_t *__restrict__ inorder,
                                                           uint32_t *__restrict__ out, uint64_t *__restrict__ big,
-                                                          uint32_t *__restrict__ nbig)
+                                                          uint32_t *__restrict__ nbig,
+                                                          const uint32_t *__restrict__ tctx, // first round only: the
+                                                          uint32_t *__restrict__ octx)       // items' context words
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     const bool valid = i < count;
@@ -164,7 +166,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
     const uint32_t r_prev = __shfl_up(r, 1, 64);
     if (second_in_wave) r = 1u - r_prev;
     if (small) {
-        out[slot[a + r]] = (uint32_t)pi;
+        const uint32_t dst = slot[a + r];
+        out[dst] = (uint32_t)pi;
+        // the context word a finished item brought along from round 0 (key payload) spares the placement step a
+        // random text gather; items that stay tied past this round get theirs gathered there
+        if (tctx) octx[dst] = tctx[i];
         big[i] = 0;
     } else if (valid) {
         big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
@@ -503,7 +509,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
                                                            int cmp_shift, const uint64_t *__restrict__ tex,
                                                            uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
                                                            uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
-                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ octx)
+                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ octx,
+                                                           uint32_t *__restrict__ nctx)
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -559,7 +566,8 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
             nslot[ni] = (uint32_t)(i0 + e);
             nseg[ni] = sid;
             if ((hm >> e) & 1u) nsegstart[sid] = ni;
-            cw[e] = 0; // tied so far: its context word is gathered at placement
+            if (nctx) nctx[ni] = cw[e]; // travels with the tied item through the first refinement round (k_seg_finish)
+            cw[e] = 0;                  // tied so far: written when the item is finished, else gathered at placement
         }
     }
     if (valid == FC_ITEMS) {
@@ -727,8 +735,10 @@ int fc_read_total(kiss_hip_ctx *ctx, const uint64_t *d_total, uint64_t *tot)
 template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
-               uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr)
+               uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr, uint32_t *nctx = nullptr,
+               bool *nctx_written = nullptr)
 {
+    if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
     const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
     KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
@@ -736,8 +746,11 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
         hipLaunchKernelGGL(k_fch_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream,
                            reinterpret_cast<const uint8_t *>(key), pos, count, tex, npos, nslot, nseg, nsegstart);
     else if (SRC == FC_KEY && !HAS_SLOT && !last_round && out && octx && !isa && cmp_shift >= 24)
+    {
         hipLaunchKernelGGL(k_fc0_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, pos, count, cmp_shift, tex,
-                           npos, nslot, nseg, nsegstart, out, octx);
+                           npos, nslot, nseg, nsegstart, out, octx, nctx);
+        if (nctx_written) *nctx_written = nctx != nullptr;
+    }
     else
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa, octx);
@@ -845,8 +858,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
     uint64_t *F1 = ctx->flags;
     uint64_t *F2 = ctx->flags + ctx->t_cap;
+    bool have_tctx = false; // bslot is free until the big-segment path of the first round: the tied items' context words
     KTRY((fc_compact<FC_KEY, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
-                                   ctx->lms_sorted_far, nullptr, ctx->lms_ctx_far)));
+                                   ctx->lms_sorted_far, nullptr, ctx->lms_ctx_far, ctx->bslot, &have_tctx)));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     if (dbg)
@@ -883,7 +897,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             hipLaunchKernelGGL(k_seg_adjacent, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Gc, SSc, count, off,
                                depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
-                               count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig);
+                               count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig,
+                               (have_tctx && off == ROUND0_BASES) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
