@@ -136,6 +136,61 @@ def test_orchestration_two_ranks_gloo_cpu(n, k):
     assert q.get(timeout=5) is True
 
 
+class DeepTieBackend(OracleBackend):
+    """stand-in whose exact-order sort reports ties too deep on ONE rank (what kiss_hip_stage_sort does with
+    KISS_HIP_E_DEEP): the orchestration has to agree on the k = 256 rerun and finish on rank 0 by refine_exact"""
+
+    def __init__(self, S, k, deep_rank):
+        super().__init__(S, k)
+        self.deep_rank = deep_rank
+        self.refined = 0
+
+    def sort(self, keys, pos):
+        if self.k >= self.n and dist.get_rank() == self.deep_rank:
+            return None
+        return super().sort(keys, pos)
+
+    def refine_exact(self, SA, h0):
+        assert h0 == 256 and dist.get_rank() == 0
+        want = self.orc.suffix_sort(self.S, 256)  # the rerun delivered the 256-ordered SA
+        assert np.array_equal(SA.numpy().view(np.uint32), want)
+        self.refined += 1
+        return torch.from_numpy(self.orc.suffix_sort(self.S, 0xFFFFFFFF).view(np.int32).copy())
+
+
+def _cpu_worker_deep(rank, world, port, n, deep_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kiss_amd import multi_gpu
+        S = gen.genome_like(n, 11)
+        be = DeepTieBackend(S, 0xFFFFFFFF, deep_rank)
+        sa = multi_gpu.sharded_suffix_sort(be, n)
+        assert be.k == 0xFFFFFFFF  # restored after the rerun
+        if rank == 0:
+            from tests import oracle_binding
+            ok = be.refined == 1 and bool(np.array_equal(sa.numpy().view(np.uint32),
+                                                         oracle_binding.load().suffix_sort(S, 0xFFFFFFFF)))
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("deep_rank", [0, 1])
+def test_exact_order_deep_tie_fallback_two_ranks_gloo_cpu(deep_rank):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_cpu_worker_deep, args=(r, 2, port, 8000, deep_rank, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_splitters_balance():
     from kiss_amd.multi_gpu import choose_splitters, group_counts
     rng = np.random.default_rng(0)
