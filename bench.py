@@ -3,11 +3,22 @@
 
 A "step" is one pass of the hot path (pack -> get_lms -> k-ordered LMS sort -> induction) over one
 synthetic chm13-sized text (n = 3 117 292 070, k = 256) that is already resident in HBM when the
-timed region starts; the SA stays in HBM.  One process per GPU.  For N > 1 the default (--mode sharded) sorts ONE
-text: the LMS sort is sharded by key range over the ranks (RCCL all-to-all of the LMS list, gather of the sorted
-pieces, induction on rank 0) -> "scaling": "strong"; --mode replicas sorts one independent text per rank (no
-data-path collective) -> "scaling": "weak".  If the sharded exchange fails, the run falls back to replicas and says so
-(config.sharded_error).
+timed region starts; the SA stays in HBM.  One process per GPU.
+
+Launch forms:
+  python bench.py --gpus 1 ...                       one process, one GPU
+  python bench.py --gpus N ...   (WORLD_SIZE unset)  this process starts N fresh rank processes itself (one per GPU,
+                                                     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON
+                                                     line and exits with the worst child status; it never touches the GPU
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (WORLD_SIZE = N in the environment)
+                                                     this process IS one rank; --gpus must equal WORLD_SIZE
+
+For N > 1 the default (--mode sharded) sorts ONE text: the LMS sort is sharded by key range over the ranks (RCCL
+all-to-all of the LMS list, gather of the sorted pieces, induction on rank 0) -> "scaling": "strong"; --mode replicas
+sorts one independent text per rank (no data-path collective) -> "scaling": "weak".  A rank that fails exits non-zero;
+nothing is retried inside a process group whose collective has failed.  Only the self-launching parent may start a
+FRESH set of rank processes in --mode replicas after a sharded failure, and the line then says "scaling": "weak" and
+carries config.sharded_error.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description).
 """
@@ -121,6 +132,91 @@ def cpu_baseline(S_host_sample, k):
             "sample": "first %d bases of the same synthetic text, k=%d, %.1f s" % (S_host_sample.size, k, dt)}
 
 
+EXIT_TOO_FEW_DEVICES = 3  # a rank found fewer visible GPUs than --gpus: never retried, never a silent 1-GPU number
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv, child_cmd=None, timeout=None):
+    """Starts n_ranks fresh processes of this script (or `child_cmd`, a test stub), one per LOCAL_RANK, waits for all,
+    and returns (worst exit status, rank 0's stdout).  The parent never imports torch and never touches HIP.  As soon
+    as one rank exits non-zero the others are terminated (they would otherwise wait in a collective)."""
+    import subprocess
+    port = free_port()
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    t0 = time.time()
+    worst = 0
+    live = set(range(n_ranks))
+    out0 = ""
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                print("[bench] rank %d exited with status %d" % (r, rc), file=sys.stderr, flush=True)
+                worst = rc if worst == 0 or rc == EXIT_TOO_FEW_DEVICES else worst
+        if (worst != 0 or (timeout and time.time() - t0 > timeout)) and live:
+            if worst == 0:
+                print("[bench] ranks %s still running after %.0f s: terminating" % (sorted(live), timeout),
+                      file=sys.stderr, flush=True)
+                worst = 124
+            time.sleep(2.0)  # let the other ranks report their own error first
+            for r in live:
+                procs[r].terminate()  # exact PIDs we started
+            for r in live:
+                try:
+                    procs[r].wait(20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            live.clear()
+            break
+        if live:
+            if procs[0].stdout is not None and 0 in live:
+                pass  # rank 0 prints one line at the very end: read after exit (pipe buffer is ample)
+            time.sleep(0.05)
+    if procs[0].stdout is not None:
+        try:
+            out0 = procs[0].stdout.read()
+        except Exception:  # noqa: BLE001
+            out0 = ""
+    return worst, out0
+
+
+def parent_main(args, argv, child_cmd=None):
+    """--gpus N > 1 without a launcher: be the launcher."""
+    rc, out0 = launch_ranks(args.gpus, argv, child_cmd=child_cmd)
+    if rc == 0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        return 0
+    if rc != EXIT_TOO_FEW_DEVICES and args.mode == "sharded" and not args.no_fallback:
+        reason = "sharded run failed (a rank exited with status %d, see stderr)" % rc
+        print("[bench] %s; starting a fresh set of ranks with --mode replicas" % reason, file=sys.stderr, flush=True)
+        rc2, out0 = launch_ranks(args.gpus, list(argv) + ["--mode", "replicas", "--sharded-error", reason],
+                                 child_cmd=child_cmd)
+        if rc2 == 0:
+            sys.stdout.write(out0)
+            sys.stdout.flush()
+            return 0
+        return rc2
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +236,20 @@ def main():
                          "all-to-all (strong scaling); 'replicas' = one independent text per rank (weak scaling)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded pipeline (RCCL collectives included) even with a single rank (test aid)")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="self-launching parent only: do not start fresh --mode replicas ranks after a sharded failure")
+    ap.add_argument("--sharded-error", default=None, help=argparse.SUPPRESS)  # set by the parent on its fallback run
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher above us: start the ranks ourselves -- before torch is imported or HIP is touched
+        sys.exit(parent_main(args, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        print("[bench] --gpus %d but WORLD_SIZE=%s: refusing to report a number for a different job size"
+              % (args.gpus, env_world), file=sys.stderr, flush=True)
+        sys.exit(2)
 
     # stdout carries exactly ONE line, the JSON result: RCCL (version banner, NCCL_DEBUG output) and other libraries
     # print to file descriptor 1 as well, so everything but the result line is sent to stderr
@@ -159,6 +268,11 @@ def main():
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     else:
         world, rank, local_rank = 1, 0, 0
+    visible = torch.cuda.device_count()  # does not initialise the GPU
+    if visible < world or local_rank >= visible:
+        print("[bench] rank %d: %d GPUs asked for, %d visible: not reporting a number for a smaller job"
+              % (rank, world, visible), file=sys.stderr, flush=True)
+        sys.exit(EXIT_TOO_FEW_DEVICES)
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         if world == 1:
@@ -200,31 +314,11 @@ def main():
         def step():
             ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo, stream=stream)
 
-    sharded_error = None
-    try:
-        for _ in range(args.warmup):
-            step()
-    except Exception as e:  # noqa: BLE001
-        if not (sharded and world > 1):
-            raise
-        # The sharded path could only be rehearsed with ranks sharing one GPU.  If the real
-        # RCCL exchange fails, still report a measured number -- one independent text per GPU -- and say so.
-        sharded_error = "%s: %s" % (type(e).__name__, e)
-        print("[bench] sharded mode failed on rank %d (%s); falling back to --mode replicas" % (rank, sharded_error),
-              file=sys.stderr, flush=True)
-    if dist is not None and world > 1:
-        flag = torch.tensor([1 if sharded_error else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) and sharded:
-            sharded = False
-            sharded_error = sharded_error or "another rank failed"
-            if seed == args.seed and rank:  # replicas hold different texts
-                S = gen_text_device(n, args.seed + 1000 * rank, device) if not args.iid else S
-
-            def step():  # noqa: F811
-                ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo, stream=stream)
-            for _ in range(args.warmup):
-                step()
+    # A rank that fails here exits non-zero (the traceback goes to stderr): a process group whose collective has
+    # failed is never used again, and there is no in-process retry in another mode.
+    sharded_error = args.sharded_error  # only ever set by the self-launching parent on its fresh replicas run
+    for _ in range(args.warmup):
+        step()
 
     def barrier():
         if dist is not None:

@@ -151,23 +151,27 @@ class _Comm:
         return [int(o.item()) for o in out]
 
     def all_to_all_counts(self, send_counts):
-        s = self.torch.tensor(send_counts, dtype=self.torch.int64)
-        r = self.torch.zeros(self.world, dtype=self.torch.int64)
-        if self.stage:
-            # gloo has no all_to_all: all_gather the count rows and read our column
-            rows = [self.torch.zeros(self.world, dtype=self.torch.int64) for _ in range(self.world)]
-            self.dist.all_gather(rows, s, group=self.group)
-            return [int(rows[src][self.rank].item()) for src in range(self.world)]
-        dev = self.torch.device("cuda", self.torch.cuda.current_device())
-        s, r = s.to(dev), r.to(dev)
-        self.dist.all_to_all_single(r, s, group=self.group)
-        return [int(x) for x in r.tolist()]
+        """-> (recv_counts, largest count of the whole G x G matrix).  The full matrix is all-gathered (G^2 integers)
+        so that every rank derives the SAME transport decision from it in all_to_all()."""
+        s = self.torch.tensor([int(c) for c in send_counts], dtype=self.torch.int64)
+        rows = [self.torch.zeros(self.world, dtype=self.torch.int64) for _ in range(self.world)]
+        if not self.stage:
+            dev = self.torch.device("cuda", self.torch.cuda.current_device())
+            s = s.to(dev)
+            rows = [r.to(dev) for r in rows]
+        self.dist.all_gather(rows, s, group=self.group)
+        mat = [[int(x) for x in row.tolist()] for row in rows]
+        return [mat[src][self.rank] for src in range(self.world)], max(max(row) for row in mat)
 
-    def all_to_all(self, out, inp, out_splits, in_splits):
+    def use_collective(self, esz, largest_count):
+        """One decision for all ranks: a single all_to_all_single only if EVERY pair's message fits MAX_MSG_BYTES
+        (judged on the largest entry of the all-gathered count matrix, identical everywhere)."""
+        return self.world > 1 and int(largest_count) * esz <= self.MAX_MSG_BYTES
+
+    def all_to_all(self, out, inp, out_splits, in_splits, largest_count):
         if not self.stage:
             esz = inp.element_size()
-            biggest = max([0] + [int(c) * esz for c in list(out_splits) + list(in_splits)])
-            if self.world > 1 and biggest <= self.MAX_MSG_BYTES:
+            if self.use_collective(esz, largest_count):
                 self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
                                             group=self.group)
                 return out
@@ -308,12 +312,12 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     send_counts = group_counts(local_hist, splitters, G)
     skeys, spos = backend.partition(keys, pos, HIST_BITS, splitters, G)
     # the exchange: all-to-all of (key, position), receiver keeps source-rank order
-    recv_counts = comm.all_to_all_counts(send_counts)
+    recv_counts, largest = comm.all_to_all_counts(send_counts)
     R = int(sum(recv_counts))
     rkeys = backend.empty(R, torch.int64)
     rpos = backend.empty(R, torch.int32)
-    comm.all_to_all(rkeys, skeys, recv_counts, send_counts)
-    comm.all_to_all(rpos, spos, recv_counts, send_counts)
+    comm.all_to_all(rkeys, skeys, recv_counts, send_counts, largest)
+    comm.all_to_all(rpos, spos, recv_counts, send_counts, largest)
     res = backend.sort(rkeys, rpos)
     if int(backend.k) >= n:
         # exact order: a rank whose key range holds ties deeper than the bounded-round path handles (tandem arrays of

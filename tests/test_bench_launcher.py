@@ -1,0 +1,82 @@
+"""bench.py --gpus N without a launcher starts N ranks itself (ADVICE bench.py:126): driven here on
+CPU with a stub child.  The parent must never import torch, must relay exactly rank 0's line, exit non-zero when a rank
+does, and must not report anything for a job smaller than the one asked for."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = [sys.executable, os.path.join(ROOT, "tests", "bench_stub_child.py")]
+
+
+def _bench():
+    import importlib
+    sys.modules.pop("bench", None)
+    return importlib.import_module("bench")
+
+
+def test_launch_ranks_relays_rank0_line(monkeypatch):
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "ok")
+    rc, out = bench.launch_ranks(4, ["--gpus", "4", "--steps", "2"], child_cmd=STUB)
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["argv"] == ["--gpus", "4", "--steps", "2"]
+
+
+def test_launch_ranks_failure_terminates_peers_and_is_nonzero(monkeypatch):
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "fail_rank1")
+    t0 = time.time()
+    rc, out = bench.launch_ranks(2, [], child_cmd=STUB)
+    assert rc == 7 and out.strip() == ""
+    assert time.time() - t0 < 30  # rank 0 was terminated, not waited for
+
+
+def test_too_few_devices_code_wins(monkeypatch):
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "too_few")
+    rc, out = bench.launch_ranks(2, [], child_cmd=STUB)
+    assert rc == bench.EXIT_TOO_FEW_DEVICES and out.strip() == ""
+
+
+def test_parent_never_imports_torch_and_gpus_mismatch_fails():
+    # a process that is asked for --gpus 2 with WORLD_SIZE=4 refuses (before importing torch)
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+    assert "| torch" not in p.stderr and p.stdout.strip() == ""
+
+
+def test_gpus_2_on_a_box_without_2_gpus_exits_nonzero_with_reason():
+    # real children: here (no GPU) and on a 1-GPU box both ranks see fewer than 2 devices
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--text-len", "100000", "--steps", "1",
+                        "--warmup", "0", "--cpu-sample", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3, p.stderr[-1500:]
+    assert p.stdout.strip() == "" and "GPUs asked for" in p.stderr
+    assert "replicas" not in p.stderr  # no fallback run for a box that is simply too small
+
+
+def test_parent_fallback_starts_fresh_replica_ranks_and_says_so(monkeypatch, capsys):
+    import argparse
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "fail_sharded_only")
+    args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=False)
+    rc = bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB)
+    assert rc == 0
+    d = json.loads(capsys.readouterr().out.strip())
+    assert d["scaling"] == "weak" and "status 9" in d["sharded_error"] and d["n_gpus"] == 2
+    # --no-fallback: the failure is the result
+    args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=True)
+    assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == 9

@@ -83,7 +83,10 @@ class OracleBackend:
 
     def sort(self, keys, pos):
         p = pos.numpy().view(np.uint32)
-        assert np.all(np.diff(p.astype(np.int64)) > 0) or p.size < 2 or True
+        # the received list is the concatenation, in source-rank order, of the ranks' ascending window lists filtered
+        # by key range; the windows are disjoint and ordered by rank, so the whole list ascends by text position --
+        # that is what keeps the index tie-break of the comparator alive across the exchange
+        assert p.size < 2 or np.all(np.diff(p.astype(np.int64)) > 0), "exchange broke ascending position order"
         out = torch.from_numpy(self.orc.lms_sort(self.S, self.k, p).view(np.int32).copy())
         return out, torch.zeros_like(out)  # no context words: "gather them"
 
@@ -189,6 +192,40 @@ def test_exact_order_deep_tie_fallback_two_ranks_gloo_cpu(deep_rank):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _decision_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kiss_amd import multi_gpu
+        comm = multi_gpu._Comm()
+        comm.MAX_MSG_BYTES = 1000  # lowered so that only ONE pair of the matrix exceeds it
+        # rank 0 sends 10 items to itself and 2000 to rank 1; rank 1 sends 5 and 7: only rank 0 / the pair (0 -> 1)
+        # sees a split above the limit with 4-byte elements (the decision used to be per rank)
+        send = [10, 2000] if rank == 0 else [5, 7]
+        recv, largest = comm.all_to_all_counts(send)
+        q.put((rank, recv, largest, comm.use_collective(4, largest), comm.use_collective(4, 200)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_transport_decision_is_identical_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_decision_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got[0][1] == [10, 5] and got[1][1] == [2000, 7]
+    assert got[0][2] == got[1][2] == 2000
+    assert got[0][3] is False and got[1][3] is False  # both take the chunked point-to-point form
+    assert got[0][4] is True and got[1][4] is True
 
 
 def test_splitters_balance():
