@@ -5,16 +5,26 @@
  * libkiss_hip.so C-ABI) may include, link or call this file.  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
  *
- * PARITY STATUS: "parity unpinned".  The reference's hot-path headers include
- * <spdlog/spdlog.h>, an un-vendored submodule that is absent from
- * /root/reference/submodules/spdlog and from this image, so the reference is
- * unbuildable here without a stand-in header (not allowed); and the reference's
- * own tests (tests/kiss.cpp:26-28) hold only the k-order *property* on unseeded
- * random strings -- no golden vectors.  The oracle is therefore pinned by
- *   (a) that property (tests/test_oracle.py), and
- *   (b) for k = 2^32-1, equality with the unique true suffix array computed by an
- *       independent naive sorter,
- * and every function below cites the reference lines it restates.
+ * PARITY STATUS: pinned against the reference's own compiled code for get_lms,
+ * the packed-text loads, put_lms_suffix and the induction sweeps; NOT pinned by
+ * reference code for the control flow of the LMS sort (kiss1_core.hpp:41-144), for
+ * KISS2 and for the FM-index ("parity unpinned" for those three).  Detail:
+ *   - kiss1_core.hpp, kiss2_core.hpp and fm_index.hpp include <spdlog/spdlog.h>, an
+ *     un-vendored submodule absent from /root/reference/submodules/spdlog and from
+ *     this image; they are unbuildable here and no stand-in header is written.
+ *   - kiss_common.hpp, structs.hpp, utils.hpp, constant.hpp and xbit_vector.hpp
+ *     need nothing the image lacks: oracle/ref_driver.cpp compiles them where they
+ *     lie into oracle/_ref/libkiss_ref.so, and tests/test_ref_pin.py +
+ *     tests/golden/ref_pins.json (made by tests/golden/make_ref_golden.py) check
+ *     this file against them: LMS list + 5x256 histograms (1/3/8 threads), 10-mer
+ *     and 125-base loads, and the SA produced by the reference's put_lms_suffix +
+ *     induced_sort from this file's LMS order -- bit for bit.
+ *   - the comparator (kiss1_core.hpp:94-135) is restated twice, independently: here
+ *     with byte compares, in ref_driver.cpp with AVX2 block compares on the
+ *     reference's PackedDNAString loads under libstdc++'s std::sort; the two agree
+ *     on every pinned shape.  The reference's own tests (tests/kiss.cpp:26-28) hold
+ *     only the k-order property; test_oracle.py checks it, and for k = 2^32-1
+ *     equality with a naive sorter (the exact SA is unique).
  *
  * All citations are relative to /root/reference/include/biovoltron/.
  */

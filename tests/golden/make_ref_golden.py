@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_pins.json from oracle/_ref/libkiss_ref.so, i.e. from the REFERENCE'S OWN get_lms /
+put_lms_suffix / induced_sort compiled unmodified from /root/reference (see oracle/ref_driver.cpp for the one stage --
+the LMS sort of kiss1_core.hpp, which needs spdlog -- that is restated there).  Run in the container that holds
+/root/reference; the JSON (data only: generator recipe, sizes, FNV-1a-64 hashes) travels, the reference does not.
+
+Each entry: how to regenerate the input with tests/gen.py, k, m, and the FNV-1a-64 of the u32-LE arrays
+  lms_asc   : ascending LMS list incl. the sentinel          (reference get_lms)
+  lms_sorted: k-ordered LMS list, sentinel first             (kref_lms_sort == oracle, asserted equal here)
+  sa        : the suffix array                               (reference put_lms_suffix + induced_sort)
+An entry is only written if the oracle (oracle/kiss_oracle.c) produced identical arrays."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from tests import gen, oracle_binding, ref_binding  # noqa: E402
+
+
+def make_input(recipe):
+    kind = recipe[0]
+    if kind == "iid":
+        return gen.iid(recipe[1], recipe[2])
+    if kind == "genome_like":
+        return gen.genome_like(recipe[1], recipe[2])
+    if kind == "periodic":
+        return gen.periodic(recipe[1], recipe[2], recipe[3], mutations=recipe[4])
+    if kind == "endrepeat":  # iid text followed by a copy of its first `cut` bases
+        base = gen.iid(recipe[1], recipe[2])
+        return np.concatenate([base, base[:recipe[3]]])
+    if kind == "const":
+        return np.full(recipe[1], recipe[2], np.uint8)
+    if kind == "abcd_as_dna":  # the reference's own general-alphabet test draws 'A'..'D' (tests/kiss.cpp:51-69): as codes
+        return gen.iid(recipe[1], recipe[2])
+    raise ValueError(kind)
+
+
+RECIPES = [
+    ["iid", 150_000, 42],              # tests/kiss.cpp:11-29 shape (100-200 k random bases, k = 256)
+    ["iid", 15_000_000, 43],           # tests/kiss.cpp:31-49 shape (10-20 M random bases, k = 256)
+    ["genome_like", 2_000_000, 4],
+    ["genome_like", 12_000_000, 5],
+    ["periodic", 300_000, 1, 21, 6],
+    ["periodic", 300_000, 3, 22, 6],
+    ["periodic", 300_000, 37, 23, 20],
+    ["periodic", 300_000, 171, 24, 200],
+    ["periodic", 300_000, 400, 25, 6],
+    ["const", 100_000, 0],
+    ["const", 100_000, 3],
+    ["endrepeat", 200_000, 31, 124], ["endrepeat", 200_000, 32, 125], ["endrepeat", 200_000, 33, 126],
+    ["endrepeat", 200_000, 34, 256], ["endrepeat", 200_000, 35, 257], ["endrepeat", 200_000, 36, 374],
+    ["endrepeat", 200_000, 37, 375], ["endrepeat", 200_000, 38, 376], ["endrepeat", 200_000, 39, 1000],
+    ["iid", 1, 1], ["iid", 2, 2], ["iid", 5, 3], ["iid", 16, 4], ["iid", 50, 5], ["iid", 1000, 6], ["iid", 100_003, 7],
+]
+
+if __name__ == "__main__":
+    orc, ref = oracle_binding.load(), ref_binding.load()
+    T = min(8, ref.max_threads())
+    pins = []
+    for recipe in RECIPES:
+        S = make_input(recipe)
+        lms_asc, _ = ref.get_lms(S, T)
+        assert np.array_equal(lms_asc, orc.get_lms(S)[0]), recipe
+        ks = (256,) if S.size > 5_000_000 else (32, 256, 0xFFFFFFFF)
+        for k in ks:
+            sa_o, lms_o = orc.suffix_sort(S, k, stages=True)
+            sa_r, lms_r = ref.suffix_sort(S, k, T=T, stages=True)                # restated LMS sort + reference induction
+            sa_r2 = ref.suffix_sort(S, k, T=T, sorted_lms=lms_o)                  # reference code only, oracle's LMS order
+            assert np.array_equal(lms_o, lms_r) and np.array_equal(sa_o, sa_r) and np.array_equal(sa_o, sa_r2), (recipe, k)
+            pins.append({"recipe": recipe, "n": int(S.size), "k": int(k), "m": int(lms_r.size),
+                         "lms_asc_fnv": "%016x" % orc.fnv(lms_asc), "lms_sorted_fnv": "%016x" % orc.fnv(lms_r),
+                         "sa_fnv": "%016x" % orc.fnv(sa_r)})
+            print(recipe, k, pins[-1]["sa_fnv"], flush=True)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_pins.json"), "w") as f:
+        json.dump({"made_by": "tests/golden/make_ref_golden.py", "threads": T, "pins": pins}, f, indent=1)
+    print("wrote", len(pins), "pins")
