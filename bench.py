@@ -120,6 +120,168 @@ def gen_text_device(n, seed, device):
     return S
 
 
+FULL_SIZE_PINS = os.path.join(ROOT, "tests", "golden", "full_size_pins.json")
+
+
+def verify_leg(ctx, S, SA, n, k, seed, iid, algo, with_fnv):
+    """After the timed region: the LAST suffix array is checked on the device (kiss_hip_ctx_verify_sa_dev: permutation,
+    SA[0] = n, the reference's own k-order test for every adjacent pair -- or, for k >= n, the linear-time proof of
+    exactness) and hashed.  `sa_fnv1a64` (FNV-1a-64 over the u32-LE bytes, the hash the full-size oracle comparisons of
+    tools/full_parity.py record) is compared with the committed value when the run is the pinned configuration."""
+    import torch
+    from kiss_amd import sorter
+    rep = ctx.verify_sa_dev(S.data_ptr(), n, SA.data_ptr(), k)
+    out = {"verified": bool(rep["ok"]), "verify": {kk: rep[kk] for kk in ("exact", "sa0_ok", "out_of_range", "duplicates",
+                                                                         "order_violations", "tied_pairs")},
+           "sa_digest": "%016x" % rep["digest"]}
+    out["verify"]["ms"] = rep["ms"]
+    out["verify"]["what"] = ("k >= n: proof that SA is THE suffix array" if rep["exact"] else
+                             "SA[0] = n, permutation, substr(SA[i-1], k) <= substr(SA[i], k) for all i (tests/kiss.cpp:26-28)")
+    key = None
+    if not iid and n == CHM13_N:
+        key = "chm13size_seed%d_%s" % (seed, "exact" if k >= n else "k%d" % k)
+    pins = {}
+    if os.path.exists(FULL_SIZE_PINS):
+        with open(FULL_SIZE_PINS) as f:
+            pins = json.load(f)
+    pin = pins.get(key) if key else None
+    if with_fnv:
+        t0 = time.perf_counter()
+        chunk = 64 << 20  # u32 entries per piece
+        buf = torch.empty(chunk, dtype=torch.int32, pin_memory=True)
+        h = sorter.FNV1A64_SEED
+        for a in range(0, n + 1, chunk):
+            b = min(n + 1, a + chunk)
+            buf[:b - a].copy_(SA[a:b])
+            h = sorter.fnv1a64(buf[:b - a].numpy(), h)
+        out["sa_fnv1a64"] = "%016x" % h
+        out["verify"]["fnv_seconds"] = time.perf_counter() - t0
+    if pin:
+        out["sa_pinned"] = {"key": key, "digest": pin.get("digest"), "sa_fnv1a64": pin.get("sa_fnv1a64"),
+                            "source": pin.get("source")}
+        ok = pin.get("digest") in (None, out["sa_digest"])
+        if with_fnv and pin.get("sa_fnv1a64"):
+            ok = ok and pin["sa_fnv1a64"] == out["sa_fnv1a64"]
+        out["sa_matches_pinned_hash"] = bool(ok)
+        out["verified"] = out["verified"] and bool(ok)
+    return out
+
+
+def end_to_end_leg(ctx, S, n, k, algo, reps=2):
+    """The reference's own timed region (command/suffix_sort.hpp:57-61): S in HOST memory -> SA in HOST memory, through
+    kiss_hip_ctx_suffix_sort_dna_u32.  Two host-memory kinds: page-locked (what a host that cooperates allocates; the
+    PCIe-limited number) and pageable (what kiss::vector / numpy hand over: 8 copy threads through bounce buffers)."""
+    import torch
+    res = {"region": "host S (1 byte per base) -> host SA (u32), command/suffix_sort.hpp:57-61",
+           "bytes": n + 4 * (n + 1)}
+    # PCIe rates on this box, one big page-locked copy each way
+    probe = min(n, 1 << 30)
+    hp = torch.empty(probe, dtype=torch.uint8, pin_memory=True)
+    dp = torch.empty(probe, dtype=torch.uint8, device=S.device)
+    for direction in ("h2d", "d2h"):
+        best = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if direction == "h2d":
+                dp.copy_(hp, non_blocking=True)
+            else:
+                hp.copy_(dp, non_blocking=True)
+            torch.cuda.synchronize()
+            best = max(best, probe / (time.perf_counter() - t0) / 1e9)
+        res["pcie_%s_GBps" % direction] = best
+    del hp, dp
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            S_h = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            SA_h = torch.empty(n + 1, dtype=torch.int32, pin_memory=True)
+        else:
+            S_h = torch.empty(n, dtype=torch.uint8)
+            SA_h = torch.empty(n + 1, dtype=torch.int32)
+        S_h.copy_(S)
+        torch.cuda.synchronize()
+        S_np, SA_np = S_h.numpy(), SA_h.numpy().view(np.uint32)
+        best = None
+        for r in range(reps + 1):  # the first call allocates the ctx-owned device copies (and faults SA_h in): not timed
+            t0 = time.perf_counter()
+            ctx.suffix_sort_host(S_np, SA_np, k=k, algo=algo)
+            dt = time.perf_counter() - t0
+            st = ctx.stats()
+            cur = {"ms": 1e3 * dt, "bases_per_s": n / dt, "h2d_ms": st["ms_h2d"], "device_ms": st["ms_total"],
+                   "d2h_ms": st["ms_d2h"]}
+            if r and (best is None or cur["ms"] < best["ms"]):
+                best = cur
+        res[kind] = best
+        del S_np, SA_np, S_h, SA_h
+    floor = 1e3 * (n / (res["pcie_h2d_GBps"] * 1e9) + 4.0 * (n + 1) / (res["pcie_d2h_GBps"] * 1e9)) + res["pinned"]["device_ms"]
+    res["floor_ms"] = floor
+    res["floor_note"] = "bytes / measured PCIe rate per direction + device time, no overlap"
+    res["pinned_over_floor"] = res["pinned"]["ms"] / floor
+    return res
+
+
+def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
+    """BASELINE.json configs[2] (second metric): FM-index queries/s, batched get_range + get_offsets of 1 M x 32-base
+    patterns on a dm-sized index, index and patterns resident in HBM; parity of ranges / hit totals / checksum against
+    the oracle on ALL patterns (single thread, like the reference's loop, fmindex_query.hpp:79-95)."""
+    import torch
+    import kiss_amd.fm_index as fm
+    from tests import oracle_binding
+    S = gen_text_device(n, 1, device)
+    S_host = S.cpu().numpy()
+    del S
+    f = fm.FMIndex(device=device.index or 0).build(S_host)
+    rng = np.random.default_rng(3)
+    pos = rng.integers(0, n - L, Q)
+    pats = S_host[pos[:, None] + np.arange(L)[None, :]]
+    mut = rng.random(Q) < 0.1
+    col = rng.integers(0, L, Q)
+    pats[mut, col[mut]] = (pats[mut, col[mut]] + 1 + rng.integers(0, 3, int(mut.sum()))) % 4
+    pats = np.ascontiguousarray(pats, dtype=np.uint8)
+    d_p = torch.from_numpy(pats).to(device)
+    f._context(max(f.N, 4 * Q)).set_profiling(True)
+    r = f.query_batch(None, want_offsets=False, d_patterns=d_p)
+    torch.cuda.synchronize()
+    kms0 = f._ctx.stats()["kernels"]["fm_query"]["ms"]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = f.query_batch(None, want_offsets=False, d_patterns=d_p)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    kernel_s = 1e-3 * (f._ctx.stats()["kernels"]["fm_query"]["ms"] - kms0) / steps
+    hits = r["total_hits"]
+    index_bytes = sum(int(getattr(f, a).numel() * getattr(f, a).element_size()) for a in ("bwt", "occ1", "occ2", "sa", "b", "b_occ"))
+    own = 48.0 * L * Q + 8.0 * hits          # this formulation: 2 LF steps of 24 B per character; range-wise locate
+    survey = 48.0 * L * Q + 64.0 * hits      # SURVEY.md 8(d): 1 536 B + 64 B per hit for a 32-base pattern
+    IC_GATHER_GBS = 8600.0  # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows (Infinity Cache)
+    out = {"metric": "FM-index queries/sec (batched get_range + get_offsets, %d-base patterns)" % L,
+           "value": Q * steps / el, "unit": "queries/s", "queries": Q, "steps": steps, "ms_per_step": 1e3 * el / steps,
+           "kernel_ms_per_step": 1e3 * kernel_s, "hits": hits, "checksum": r["checksum"], "index_n": n,
+           "index_bytes": index_bytes,
+           "roofline": {"bound": "infinity_cache", "peak": IC_GATHER_GBS, "unit": "GB/s",
+                        "peak_source": "MI355X_MICROARCH.md, gather of uniformly random rows from a 38 MB table",
+                        "note": "the %.0f MB index is resident in the 256 MiB Infinity Cache: nothing here is an HBM "
+                                "rate; every LF step is a dependent random 64-byte-sector read" % (index_bytes / 1e6),
+                        "achieved_own_model": own / kernel_s / 1e9, "frac_own_model": own / kernel_s / 1e9 / IC_GATHER_GBS,
+                        "own_model": "48 L per pattern + 8 B per hit",
+                        "achieved_survey_8d_model": survey / kernel_s / 1e9,
+                        "frac_survey_8d_model": survey / kernel_s / 1e9 / IC_GATHER_GBS,
+                        "survey_8d_model": "48 L per pattern + 64 B per hit"}}
+    orc = oracle_binding.load()
+    t0 = time.perf_counter()
+    ref = orc.fm_build(S_host, orc.suffix_sort(S_host, 32))
+    t1 = time.perf_counter()
+    rr = ref.query_batch(pats, want_offsets=False)
+    dt = time.perf_counter() - t1
+    out["cpu_baseline"] = {"value": Q / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                           "sample": "all %d patterns, single thread like the reference loop (fmindex_query.hpp:79-95), "
+                                     "%.1f s (+ %.1f s oracle index build)" % (Q, dt, t1 - t0)}
+    out["parity_vs_oracle_all_patterns"] = bool(np.array_equal(r["beg"], rr["beg"]) and np.array_equal(r["end"], rr["end"])
+                                                and hits == rr["total_hits"] and r["checksum"] == rr["checksum"])
+    f.close()
+    return out
+
+
 def cpu_baseline(S_host_sample, k):
     """Times the CPU oracle (a port: plain C restatement of the reference algorithm, OpenMP only in the
     per-bucket LMS sort) on a bounded sample.  Reported baseline, not the optimisation target."""
@@ -236,6 +398,12 @@ def main():
                          "all-to-all (strong scaling); 'replicas' = one independent text per rank (weak scaling)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded pipeline (RCCL collectives included) even with a single rank (test aid)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last SA")
+    ap.add_argument("--no-fnv", action="store_true", help="skip the host-side FNV-1a-64 of the last SA (~15-20 s at chm13 size)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host S -> host SA leg (single GPU only)")
+    ap.add_argument("--no-fm", action="store_true", help="skip the FM-index queries/s leg (single GPU only)")
+    ap.add_argument("--fm-text-len", type=int, default=48_800_648, help="text length of the FM-index leg (default: dm size)")
+    ap.add_argument("--fm-queries", type=int, default=1_000_000)
     ap.add_argument("--no-fallback", action="store_true",
                     help="self-launching parent only: do not start fresh --mode replicas ranks after a sharded failure")
     ap.add_argument("--sharded-error", default=None, help=argparse.SUPPRESS)  # set by the parent on its fallback run
@@ -408,12 +576,21 @@ def main():
             dev_s = elapsed / args.steps
         out["path_roofline"] = {"algorithmic_bytes": path_bytes, "device_ms": 1e3 * dev_s,
                                 "achieved_GBps": path_bytes / dev_s / 1e9, "frac": path_bytes / dev_s / 1e9 / HBM_PEAK_GBS}
+        if not args.no_verify:
+            out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid, algo, with_fnv=(world == 1 and not args.no_fnv)))
+        if world == 1 and not sharded and not args.no_e2e:
+            out["end_to_end"] = end_to_end_leg(ctx, S, n, k, algo)
         if args.cpu_sample > 0 and world == 1:
             ns = min(n, args.cpu_sample)
             sample = S[:ns].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, k)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not sharded and not args.no_fm:
+            del S, SA
+            ctx.close()
+            torch.cuda.empty_cache()
+            out["fm_query"] = fm_query_leg(device, Q=args.fm_queries, n=args.fm_text_len)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if dist is not None:

@@ -47,7 +47,9 @@ typedef enum kiss_hip_status {
 /* Sorting algorithm selector; mirrors kISS::SortingAlgorithm
  * (include/utils/constant.hpp, command/suffix_sort.hpp:38-48). */
 #define KISS_HIP_ALGO_PARALLEL_SORTING 0 /* KISS1: k-ordered LMS sort (kiss1_core.hpp)   */
-#define KISS_HIP_ALGO_PREFIX_DOUBLING 1  /* KISS2: only k >= n (exact SA) is a function of the input */
+#define KISS_HIP_ALGO_PREFIX_DOUBLING 1  /* KISS2: k >= n -> exact SA by rank doubling; bounded k -> the (deterministic)
+                                            k-ordered SA of PARALLEL_SORTING: the reference's own bounded-k KISS2 output
+                                            depends on its thread count, only the k-order property is defined */
 
 /* the reference's size_type is uint32_t and EMPTY = 0xFFFFFFFF, so n + 19 < 2^32
  * (algo/sort/structs.hpp:94, constant.hpp:19-20) */
@@ -81,6 +83,10 @@ typedef struct kiss_hip_stats {
     uint32_t refine_depth;    /* bases the bounded phase ordered by (0: doubling phase not used) */
     uint32_t doubling_rounds; /* rank-doubling rounds executed */
     float ms_refine;          /* device time of the doubling phase (included in ms_total) */
+    /* host-pointer entry points only: wall-clock time of the two PCIe legs (the reference's timed region,
+     * command/suffix_sort.hpp:57-61, is host S -> host SA) */
+    float ms_h2d;             /* host S -> device */
+    float ms_d2h;             /* device SA -> host */
     uint32_t reserved_;
 } kiss_hip_stats;
 
@@ -133,7 +139,10 @@ int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes);
  */
 int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device);
 
-/* Same, on an existing ctx with host buffers (upload + sort + download). */
+/* Same, on an existing ctx with host buffers (upload + sort + download).  The device-side copies of S and SA belong
+ * to the ctx (allocated on the first call, kept for the next ones).  Page-locked host buffers (hipHostMalloc /
+ * hipHostRegister) travel at the PCIe rate in one copy each; pageable ones are moved by 8 threads through page-locked
+ * bounce buffers of the ctx.  kiss_hip_get_stats reports the wall time of both legs (ms_h2d, ms_d2h). */
 int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, int algo,
                                      uint32_t *SA);
 
@@ -142,6 +151,37 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
  * returns after the work on `stream` has completed. */
 int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo,
                                          uint32_t *d_SA, void *stream);
+
+/* ---- verification (device side; independent of the sort kernels: reads only the caller's text and SA) --------
+ * Checks that d_SA (n+1 entries) is what the reference's own tests require of a k-ordered suffix array
+ * (tests/kiss.cpp:26-28): SA[0] = n, a permutation of [0, n], and for every i >= 1
+ *   S.substr(SA[i-1], k) <= S.substr(SA[i], k).
+ * For k >= n the stronger linear-time proof of exactness is used instead (inverse SA; first character, then the rank
+ * of the following suffix), which holds iff d_SA is THE suffix array.  Text bytes compare as unsigned values, so the
+ * call serves both the DNA codes 0..3 and byte texts (kiss_hip_suffix_sort_u8).  `digest` is an order-sensitive
+ * 64-bit sum that any host can recompute (kiss_hip_sa_digest_host).  Allocates its own scratch (n/8 bytes, plus
+ * 4(n+1) bytes for k >= n) and frees it before returning; the ctx is only used for the device and the stream. */
+typedef struct kiss_hip_verify_report {
+    uint64_t n;
+    uint32_t k;
+    uint32_t exact;            /* 1: the k >= n proof was used */
+    uint32_t ok;               /* 1: every check passed */
+    uint32_t sa0_ok;           /* SA[0] == n */
+    uint64_t out_of_range;     /* entries > n */
+    uint64_t duplicates;       /* entries whose value occurred before */
+    uint64_t order_violations; /* adjacent pairs in the wrong order */
+    uint64_t first_violation;  /* smallest such index i (pair SA[i-1], SA[i]); meaningful if order_violations > 0 */
+    uint64_t tied_pairs;       /* bounded k: adjacent pairs equal through k bases (their order is not constrained) */
+    uint64_t digest;
+    float ms;                  /* device time of the checks */
+    uint32_t reserved_;
+} kiss_hip_verify_report;
+int kiss_hip_ctx_verify_sa_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, const uint32_t *d_SA,
+                               kiss_hip_verify_report *out, void *stream);
+/* host helpers (no device): the digest above, and FNV-1a-64 over raw bytes (seed 0xcbf29ce484222325 to start, or the
+ * previous return value to continue over the next chunk) */
+uint64_t kiss_hip_sa_digest_host(const uint32_t *SA, uint64_t count);
+uint64_t kiss_hip_fnv1a64_host(const void *data, uint64_t bytes, uint64_t seed);
 
 /* Stage outputs of the LAST sort on this ctx, for stage-level parity tests
  * (get_lms: kiss_common.hpp:543-579; lms_suffix_direct_sort_dna: kiss1_core.hpp:24-145).

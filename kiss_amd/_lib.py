@@ -34,7 +34,8 @@ class Stats(ctypes.Structure):
         ("ms_kernel", ctypes.c_float * 16), ("launches_kernel", ctypes.c_uint64 * 16),
         ("items_kernel", ctypes.c_uint64 * 16),
         ("refine_items", ctypes.c_uint64), ("refine_depth", ctypes.c_uint32), ("doubling_rounds", ctypes.c_uint32),
-        ("ms_refine", ctypes.c_float), ("reserved_", ctypes.c_uint32),
+        ("ms_refine", ctypes.c_float), ("ms_h2d", ctypes.c_float), ("ms_d2h", ctypes.c_float),
+        ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self):
@@ -44,6 +45,18 @@ class Stats(ctypes.Structure):
             for i, name in enumerate(KERNEL_CLASSES)
         }
         return d
+
+
+class VerifyReport(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint64), ("k", ctypes.c_uint32), ("exact", ctypes.c_uint32), ("ok", ctypes.c_uint32),
+        ("sa0_ok", ctypes.c_uint32), ("out_of_range", ctypes.c_uint64), ("duplicates", ctypes.c_uint64),
+        ("order_violations", ctypes.c_uint64), ("first_violation", ctypes.c_uint64), ("tied_pairs", ctypes.c_uint64),
+        ("digest", ctypes.c_uint64), ("ms", ctypes.c_float), ("reserved_", ctypes.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved_"}
 
 
 class FmiView(ctypes.Structure):
@@ -91,6 +104,12 @@ def load():
     lib.kiss_hip_ctx_suffix_sort_dna_u32.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp]
     lib.kiss_hip_ctx_suffix_sort_dna_u32_dev.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, vp]
     lib.kiss_hip_ctx_get_stage_outputs.argtypes = [vp, vp, vp, vp]
+    lib.kiss_hip_ctx_verify_sa_dev.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp, ctypes.POINTER(VerifyReport), vp]
+    lib.kiss_hip_ctx_verify_sa_dev.restype = ctypes.c_int
+    lib.kiss_hip_sa_digest_host.argtypes = [vp, ctypes.c_uint64]
+    lib.kiss_hip_sa_digest_host.restype = ctypes.c_uint64
+    lib.kiss_hip_fnv1a64_host.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64]
+    lib.kiss_hip_fnv1a64_host.restype = ctypes.c_uint64
     lib.kiss_hip_debug_radix_sort.argtypes = [vp, vp, vp, ctypes.c_uint64, ctypes.c_int]
     lib.kiss_hip_debug_scan_u32.argtypes = [vp, vp, ctypes.c_uint64]
     u64 = ctypes.c_uint64
@@ -143,7 +162,8 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_version", "kiss_hip_strerror", "kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy",
     "kiss_hip_ctx_set_profiling", "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
     "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32_dev",
-    "kiss_hip_ctx_get_stage_outputs", "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
+    "kiss_hip_ctx_get_stage_outputs", "kiss_hip_ctx_verify_sa_dev", "kiss_hip_sa_digest_host", "kiss_hip_fnv1a64_host",
+    "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
     "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
     "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
     "kiss_hip_stage_sort", "kiss_hip_stage_induce", "kiss_hip_stage_refine_exact",

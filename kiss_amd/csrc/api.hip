@@ -5,6 +5,7 @@
 //   pack -> get_lms -> k-ordered LMS sort -> (near-end rule, merge, context gather) -> L/S induction.
 #include "kiss_internal.hpp"
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -92,11 +93,14 @@ void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
     void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
-                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->pairs1, ctx->pairs2, ctx->rx_ctl};
+                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->pairs1, ctx->pairs2, ctx->rx_ctl};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : ctx->fm_pool)
         if (p) (void)hipFree(p);
+    if (ctx->io_S) (void)hipFree(ctx->io_S);
+    if (ctx->io_SA) (void)hipFree(ctx->io_SA);
+    kiss_xfer_free(ctx);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto &e : ctx->ev_pool) {
         (void)hipEventDestroy(e.a);
@@ -128,9 +132,11 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
     if ((uint64_t)k >= n) depth = 0;
     else depth = (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
     if (algo == KISS_HIP_ALGO_PREFIX_DOUBLING && depth != 0) {
-        // KISS2 with bounded k is not a function of its input (thread-count dependent ties); only the
-        // exact-order case is defined.
-        return KISS_HIP_E_UNSUPPORTED;
+        // KISS2 with bounded k (kiss2_core.hpp:835-886; `suffix_sort -s PREFIX_DOUBLING` with the default k = 256,
+        // suffix_sort.hpp:38-48): the reference's result there depends on its thread count (ties at depth k land in
+        // schedule order), so the only thing it defines is the k-order property -- which the deterministic KISS1
+        // order has.  Same answer as PARALLEL_SORTING, no error.
+        algo = KISS_HIP_ALGO_PARALLEL_SORTING;
     }
     ctx->stats.depth = (uint32_t)(depth > 0xFFFFFFFFull ? 0xFFFFFFFFull : depth);
     // PREFIX_DOUBLING: a bounded-depth phase (order h0, the k-ordered pipeline) followed by rank doubling over
@@ -207,6 +213,14 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
 }
 
 } // namespace
+
+// CTX (4 bytes per base: context words of the sweeps, later the inverse SA of the doubling phase) is only needed by the
+// process that runs the induction: allocated on first use, so that ranks > 0 of a sharded sort never hold it
+int kiss_need_ctx_words(kiss_hip_ctx *ctx)
+{
+    if (ctx->CTX) return KISS_HIP_OK;
+    return dmalloc(ctx, &ctx->CTX, ctx->max_n + 2);
+}
 
 int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
 {
@@ -345,13 +359,11 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
         ctx->pk_words = words;
         ctx->n_tiles_cap = words / 256 + 2;
         ctx->ind_tiles_cap = 4 * ((max_n + 1) / 2048 + 2) + 2;
-        ctx->near_cap = 65536;
 #define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
         ALLOC(pk, words);
         ALLOC(tile_gp, ctx->n_tiles_cap);
         ALLOC(tile_cnt, ctx->n_tiles_cap);
         ALLOC(d_counts, 16);
-        ALLOC(CTX, max_n + 2);
         ALLOC(ind_counts, ctx->ind_tiles_cap);
         ALLOC(rx_ctl, 4); // [0] radix ticket, [1] look-back error flag
         if (hipMemset(ctx->rx_ctl, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
@@ -360,9 +372,6 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
         }
 
         ALLOC(d_small, 64);
-        ALLOC(near_idx, ctx->near_cap);
-        ALLOC(near_fin, ctx->near_cap);
-        ALLOC(near_pos, ctx->near_cap);
 #undef ALLOC
         // LMS-sized arrays: DNA has ~0.29-0.30 n LMS suffixes; inputs with more (up to n/2) re-reserve on demand
         uint64_t m0 = (uint64_t)(0.32 * (double)max_n) + 4096;
@@ -433,33 +442,35 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
     if (!ctx || !SA || (n && !S)) return KISS_HIP_E_INVALID;
     if (n > ctx->max_n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
-    uint8_t *d_S = nullptr;
-    uint32_t *d_SA = nullptr;
-    int rc = KISS_HIP_OK;
-    do {
-        hipError_t e = hipMalloc((void **)&d_S, n ? n : 1);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_SA, (n + 1) * sizeof(uint32_t));
+    ctx->stream = ctx->own_stream;
+    if (!ctx->io_S || ctx->io_cap < n) { // device-side copies of the caller's buffers: owned by the ctx, sized for max_n
+        if (ctx->io_S) (void)hipFree(ctx->io_S);
+        if (ctx->io_SA) (void)hipFree(ctx->io_SA);
+        ctx->io_S = nullptr;
+        ctx->io_SA = nullptr;
+        ctx->ws_bytes -= ctx->io_cap ? 5 * ctx->io_cap + 4 : 0;
+        ctx->io_cap = 0;
+        const uint64_t cap = ctx->max_n ? ctx->max_n : 1;
+        hipError_t e = hipMalloc((void **)&ctx->io_S, cap);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->io_SA, (cap + 1) * sizeof(uint32_t));
         if (e != hipSuccess) {
             ctx->last_hip_error = (int)e;
-            rc = KISS_HIP_E_NOMEM;
-            break;
+            return KISS_HIP_E_NOMEM;
         }
-        if (n) e = hipMemcpy(d_S, S, n, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            ctx->last_hip_error = (int)e;
-            rc = KISS_HIP_E_HIP;
-            break;
-        }
-        if ((rc = sort_dev(ctx, d_S, n, k, algo, d_SA, nullptr))) break;
-        e = hipMemcpy(SA, d_SA, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            ctx->last_hip_error = (int)e;
-            rc = KISS_HIP_E_HIP;
-        }
-    } while (0);
-    if (d_S) (void)hipFree(d_S);
-    if (d_SA) (void)hipFree(d_SA);
-    return rc;
+        ctx->io_cap = cap;
+        ctx->ws_bytes += 5 * cap + 4;
+    }
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    KTRY(kiss_xfer_h2d(ctx, ctx->io_S, S, n));
+    const auto t1 = clk::now();
+    KTRY(sort_dev(ctx, ctx->io_S, n, k, algo, ctx->io_SA, nullptr));
+    const auto t2 = clk::now();
+    KTRY(kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t)));
+    const auto t3 = clk::now();
+    ctx->stats.ms_h2d = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    ctx->stats.ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
+    return KISS_HIP_OK;
 }
 
 int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device)

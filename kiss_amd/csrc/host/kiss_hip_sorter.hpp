@@ -74,7 +74,8 @@ struct KissHipSorter {
   }
 };
 
-// KISS2 (PREFIX_DOUBLING): defined for k >= n only (exact suffix array), see DESIGN.md section 8
+// KISS2 (PREFIX_DOUBLING): k >= n gives the exact suffix array by rank doubling; a bounded k gives the same
+// k-ordered array as KISS1 (the reference's bounded-k KISS2 output is thread-count dependent), see DESIGN.md section 8
 template <typename size_type = std::uint32_t>
 struct KissHipSorter2 : KissHipSorter<size_type> {
   using SA_t = typename KissHipSorter<size_type>::SA_t;

@@ -739,6 +739,7 @@ int verify_part(kiss_hip_ctx *ctx, const uint32_t *SA, int64_t lo, int64_t hi, u
 int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
 {
     ctx->stats.induce_passes = 0;
+    KTRY(kiss_need_ctx_words(ctx));
     uint64_t cnt[4], cntS[4], cntL[4], cntLMS[4], start[5], lms_start[5];
     start[0] = 1;
     lms_start[0] = 0;

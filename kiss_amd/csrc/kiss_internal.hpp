@@ -90,8 +90,18 @@ struct kiss_hip_ctx {
     void *fm_pool[11] = {};
     uint64_t fm_pool_cap[11] = {};
     // near-end
-    uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr;
+    uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr; // place.hip: near_reserve
     uint64_t near_cap = 0;
+
+    // host-pointer entry points: device-side copies of the caller's S / SA (allocated on first use, api.hip) and the
+    // page-locked bounce buffers + streams of the staged transfers (xfer.hip)
+    uint8_t *io_S = nullptr;
+    uint32_t *io_SA = nullptr;
+    uint64_t io_cap = 0; // bases
+    void *xf_pin[8][2] = {};
+    hipEvent_t xf_done[8][2] = {};
+    hipStream_t xf_stream[8] = {};
+    bool xf_ready = false;
 
     // state of the last call (for stage outputs / stats)
     uint64_t n = 0, m = 0, m_far = 0;
@@ -120,6 +130,8 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
 // (re)allocates the tied-segment arrays (seg*, slot*, segstart*, bkey*, bpos*, bseg*, bslot, flags) for t_cap items;
 // their contents are lost
 int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap);
+// allocates ctx->CTX (max_n + 2 words) on first use: only the process that runs the induction / doubling phase holds it
+int kiss_need_ctx_words(kiss_hip_ctx *ctx);
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
 // classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
 // only LMS suffixes / histogram contributions of text positions in [win_lo, win_hi) are produced (sharded runs)
@@ -150,6 +162,10 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
 int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
+// host <-> device legs of the host-pointer entry points (xfer.hip); both return after the bytes have arrived
+int kiss_xfer_h2d(kiss_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int kiss_xfer_d2h(kiss_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+void kiss_xfer_free(kiss_hip_ctx *ctx);
 // induced sort sweeps -> d_SA
 int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA);
 

@@ -1151,6 +1151,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     const uint64_t total = n + 1;
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    KTRY(kiss_need_ctx_words(ctx));
     uint32_t *isa = ctx->CTX; // the induction's context words are dead by now: (n + 2) u32
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     uint8_t *heads = heads_in;

@@ -4,7 +4,9 @@
 //    comparator's scalar tail (include/biovoltron/algo/sort/kiss1_core.hpp:120-134): at most k bases, then
 //    position; a suffix that runs off the text is smaller.  There are < D/2 of them.  Each is ranked
 //    against the sorted far list by binary search with the full comparator (10-mer bucket with 'A'
-//    padding, kiss1_core.hpp:41-83 + structs.hpp:175-184, then cmp), and among themselves pairwise.
+//    padding, kiss1_core.hpp:41-83 + structs.hpp:175-184, then cmp), and among themselves pairwise
+//    (a few hundred at k = 256) or, for the k in the hundred thousands and above that make them many, by a
+//    merge sort with the same comparator.
 //    Every far suffix precedes every near-end suffix in text position, so cmp(far, near) is monotone
 //    over the far list and the insertion point is unique.
 // 2. Merge far + near-end into the final list lmsP and attach the context word (the bases that precede each
@@ -110,6 +112,48 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_order(const uint64_t *__res
     near_fin[e] = ie + r;
 }
 
+// ---- large E (k in the hundred thousands and beyond, but < n): O(E log^2 E) instead of O(E^2) -------------------
+// One round of a bottom-up merge sort of suffix positions by the reference comparator: `in` holds sorted runs of
+// length `run`; every element finds its place in the merged run of length 2 * run by a binary search in the sibling
+// run (left elements count the strictly smaller right ones, right elements the left ones that are not greater: the
+// comparator is a strict total order -- ties go to the position --, so the places are distinct).
+__global__ __launch_bounds__(PL_THREADS) void k_near_merge_round(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k,
+                                                                const uint32_t *__restrict__ in, uint32_t E,
+                                                                uint32_t run, uint32_t *__restrict__ out)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t base = e / (2ull * run) * (2ull * run);
+    const uint64_t mid = base + run < E ? base + run : E, end = base + 2ull * run < E ? base + 2ull * run : E;
+    const uint32_t x = in[e];
+    if (e < mid) {
+        uint64_t lo = mid, hi = end;
+        while (lo < hi) {
+            const uint64_t md = (lo + hi) >> 1;
+            if (lms_less_full(pk, n, k, in[md], x)) lo = md + 1;
+            else hi = md;
+        }
+        out[e + (lo - mid)] = x;
+    } else {
+        uint64_t lo = base, hi = mid;
+        while (lo < hi) {
+            const uint64_t md = (lo + hi) >> 1;
+            if (!lms_less_full(pk, n, k, x, in[md])) lo = md + 1;
+            else hi = md;
+        }
+        out[(e - mid) + lo] = x;
+    }
+}
+
+// both lists are sorted by the same total order, so the insertion indexes ascend along the sorted near-end list and the
+// final index of its j-th member is simply near_idx[j] + j
+__global__ __launch_bounds__(PL_THREADS) void k_near_fin_sorted(const uint32_t *__restrict__ near_idx, uint32_t E,
+                                                               uint32_t *__restrict__ near_fin)
+{
+    const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e < E) near_fin[e] = near_idx[e] + e;
+}
+
 // merged list + context words.  near_sidx: insertion indexes sorted ascending (E entries)
 __device__ __forceinline__ uint32_t near_shift(const uint32_t *__restrict__ near_sidx, uint32_t E, uint64_t i)
 {
@@ -188,6 +232,38 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__res
 #include <algorithm>
 #include <vector>
 
+#include <cstdlib>
+
+// near_idx / near_fin / near_pos / near_tmp hold one entry per near-end suffix: 65 536 to start with, regrown for the
+// inputs that have more (a bounded k in the hundred thousands or above; the reference takes any k, kiss1_core.hpp:94-135)
+static int near_reserve(kiss_hip_ctx *ctx, uint64_t E)
+{
+    if (E <= ctx->near_cap && ctx->near_tmp) return KISS_HIP_OK;
+    uint64_t cap = ctx->near_cap ? ctx->near_cap : 65536;
+    while (cap < E) cap *= 2;
+    uint32_t **ptrs[] = {&ctx->near_idx, &ctx->near_fin, &ctx->near_pos, &ctx->near_tmp};
+    for (uint32_t **p : ptrs) {
+        if (*p) {
+            (void)hipFree(*p);
+            ctx->ws_bytes -= ctx->near_cap * sizeof(uint32_t);
+            *p = nullptr;
+        }
+    }
+    ctx->near_cap = 0;
+    for (uint32_t **p : ptrs) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, cap * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            return KISS_HIP_E_NOMEM;
+        }
+        *p = reinterpret_cast<uint32_t *>(q);
+    }
+    ctx->near_cap = cap;
+    ctx->ws_bytes += 4 * cap * sizeof(uint32_t);
+    return KISS_HIP_OK;
+}
+
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 {
     (void)depth;
@@ -195,10 +271,36 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     const uint64_t E64 = m - m_far;
     ctx->stats.near_end = E64;
     if (m == 0) return KISS_HIP_OK;
-    if (E64 > ctx->near_cap) return KISS_HIP_E_UNSUPPORTED;
+    KTRY(near_reserve(ctx, E64 ? E64 : 1));
     const uint32_t E = (uint32_t)E64;
+    // pairwise ranking is the cheapest form for the handful of near-end suffixes of k = 32 / 256 (E ~ 0.3 D); beyond
+    // this size the merge-sort form takes over.  KISS_HIP_NEAR_MERGE_MIN (test hook) moves the switch.
+    uint32_t merge_min = 4096;
+    if (const char *ev = getenv("KISS_HIP_NEAR_MERGE_MIN")) merge_min = (uint32_t)strtoul(ev, nullptr, 10);
     KTimer t(ctx, KISS_HIP_K_PLACE, m);
-    if (E > 0) {
+    const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
+    if (E > 0 && E >= merge_min) {
+        // sort the near-end suffixes among themselves, then rank them against the far list
+        const uint32_t *cur = ctx->lms_pos + m_far; // ascending text positions = runs of length 1
+        uint32_t *bufs[2] = {ctx->near_pos, ctx->near_tmp};
+        int w = 0;
+        for (uint64_t run = 1; run < E; run *= 2) {
+            hipLaunchKernelGGL(k_near_merge_round, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                               cur, E, (uint32_t)run, bufs[w]);
+            cur = bufs[w];
+            w ^= 1;
+        }
+        const uint32_t *near_sorted = cur; // E == 1: the input itself
+        hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                           ctx->lms_sorted_far, m_far, near_sorted, E, ctx->near_idx);
+        hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
+        if (m_far)
+            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0,
+                               ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_idx, E,
+                               ctx->lmsP, ctx->lmsC);
+        hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, near_sorted,
+                           ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
+    } else if (E > 0) {
         const uint32_t *near_pos = ctx->lms_pos + m_far; // ascending list: the near-end suffixes are its tail
         hipLaunchKernelGGL(k_near_rank, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
                            ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);

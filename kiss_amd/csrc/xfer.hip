@@ -1,0 +1,155 @@
+// xfer.hip -- the host <-> device legs of the host-pointer entry points (kiss_hip_ctx_suffix_sort_dna_u32 and friends).
+//
+// The reference's timed region is host S -> host SA (include/command/suffix_sort.hpp:57-61), so for a drop-in caller
+// the PCIe legs are part of the metric: 1 byte per base in, 4 bytes per base out (12.5 GB at chm13 size).
+//   * host memory that is already page-locked (hipHostMalloc / hipHostRegister, torch pin_memory): ONE async copy on the
+//     ctx stream at the full PCIe rate;
+//   * pageable memory (what `kiss::vector` / std::vector / numpy hand over): XF_THREADS worker threads, each with two
+//     page-locked bounce buffers owned by the ctx and its own stream -- the CPU copy of one chunk (and, for a freshly
+//     allocated destination, its page faults) overlaps the DMA of the previous one and the other threads' chunks.
+//     hipMemcpy on pageable memory does the same thing with ONE thread.
+// Nothing here computes: bytes are moved as they are.
+#include "kiss_internal.hpp"
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int XF_THREADS = 8;
+constexpr size_t XF_CHUNK = 16ull << 20;
+
+bool host_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc'ed memory: "invalid value", not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int xfer_pool(kiss_hip_ctx *ctx)
+{
+    if (ctx->xf_ready) return KISS_HIP_OK;
+    for (int t = 0; t < XF_THREADS; t++) {
+        if (hipStreamCreateWithFlags(&ctx->xf_stream[t], hipStreamNonBlocking) != hipSuccess) return KISS_HIP_E_HIP;
+        for (int b = 0; b < 2; b++) {
+            if (hipHostMalloc(&ctx->xf_pin[t][b], XF_CHUNK, hipHostMallocDefault) != hipSuccess) return KISS_HIP_E_NOMEM;
+            if (hipEventCreateWithFlags(&ctx->xf_done[t][b], hipEventDisableTiming) != hipSuccess) return KISS_HIP_E_HIP;
+        }
+    }
+    ctx->xf_ready = true;
+    return KISS_HIP_OK;
+}
+
+// to_device: h -> d, else d -> h
+int xfer_staged(kiss_hip_ctx *ctx, void *d, void *h, uint64_t bytes, bool to_device)
+{
+    KTRY(xfer_pool(ctx));
+    const uint64_t chunks = div_up(bytes, XF_CHUNK);
+    const int threads = (int)(chunks < (uint64_t)XF_THREADS ? chunks : XF_THREADS);
+    std::atomic<int> status{KISS_HIP_OK};
+    const int device = ctx->device;
+    auto work = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) {
+            status = KISS_HIP_E_HIP;
+            return;
+        }
+        hipStream_t st = ctx->xf_stream[t];
+        if (to_device) {
+            bool used[2] = {false, false};
+            int b = 0;
+            for (uint64_t c = (uint64_t)t; c < chunks && status == KISS_HIP_OK; c += (uint64_t)threads, b ^= 1) {
+                const uint64_t off = c * XF_CHUNK;
+                const size_t len = bytes - off < XF_CHUNK ? (size_t)(bytes - off) : XF_CHUNK;
+                if (used[b]) (void)hipEventSynchronize(ctx->xf_done[t][b]);
+                std::memcpy(ctx->xf_pin[t][b], (const char *)h + off, len);
+                if (hipMemcpyAsync((char *)d + off, ctx->xf_pin[t][b], len, hipMemcpyHostToDevice, st) != hipSuccess) {
+                    status = KISS_HIP_E_HIP;
+                    return;
+                }
+                (void)hipEventRecord(ctx->xf_done[t][b], st);
+                used[b] = true;
+            }
+        } else {
+            // software pipeline: the DMA of chunk c+1 is in flight while chunk c is copied out of its bounce buffer
+            uint64_t c = (uint64_t)t;
+            int b = 0;
+            auto issue = [&](uint64_t cc, int bb) -> bool {
+                const uint64_t off = cc * XF_CHUNK;
+                const size_t len = bytes - off < XF_CHUNK ? (size_t)(bytes - off) : XF_CHUNK;
+                if (hipMemcpyAsync(ctx->xf_pin[t][bb], (const char *)d + off, len, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    return false;
+                return hipEventRecord(ctx->xf_done[t][bb], st) == hipSuccess;
+            };
+            if (c < chunks && !issue(c, b)) {
+                status = KISS_HIP_E_HIP;
+                return;
+            }
+            for (; c < chunks && status == KISS_HIP_OK; c += (uint64_t)threads, b ^= 1) {
+                const uint64_t next = c + (uint64_t)threads;
+                if (next < chunks && !issue(next, b ^ 1)) {
+                    status = KISS_HIP_E_HIP;
+                    return;
+                }
+                if (hipEventSynchronize(ctx->xf_done[t][b]) != hipSuccess) {
+                    status = KISS_HIP_E_HIP;
+                    return;
+                }
+                const uint64_t off = c * XF_CHUNK;
+                const size_t len = bytes - off < XF_CHUNK ? (size_t)(bytes - off) : XF_CHUNK;
+                std::memcpy((char *)h + off, ctx->xf_pin[t][b], len);
+            }
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) status = KISS_HIP_E_HIP;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+    if (threads > 0) work(0);
+    for (auto &x : th) x.join();
+    return status;
+}
+
+} // namespace
+
+void kiss_xfer_free(kiss_hip_ctx *ctx)
+{
+    for (int t = 0; t < XF_THREADS; t++) {
+        for (int b = 0; b < 2; b++) {
+            if (ctx->xf_pin[t][b]) (void)hipHostFree(ctx->xf_pin[t][b]);
+            if (ctx->xf_done[t][b]) (void)hipEventDestroy(ctx->xf_done[t][b]);
+            ctx->xf_pin[t][b] = nullptr;
+            ctx->xf_done[t][b] = nullptr;
+        }
+        if (ctx->xf_stream[t]) (void)hipStreamDestroy(ctx->xf_stream[t]);
+        ctx->xf_stream[t] = nullptr;
+    }
+    ctx->xf_ready = false;
+}
+
+// Both return after the bytes have arrived.  The caller has synchronised the stream that produced / will consume the
+// device buffer (the staged form uses its own streams).
+int kiss_xfer_h2d(kiss_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!bytes) return KISS_HIP_OK;
+    if (host_is_pinned(h_src) || bytes < (1u << 20)) {
+        KCHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        return KISS_HIP_OK;
+    }
+    return xfer_staged(ctx, d_dst, const_cast<void *>(h_src), bytes, true);
+}
+
+int kiss_xfer_d2h(kiss_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!bytes) return KISS_HIP_OK;
+    if (host_is_pinned(h_dst) || bytes < (1u << 20)) {
+        KCHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        return KISS_HIP_OK;
+    }
+    return xfer_staged(ctx, const_cast<void *>(d_src), h_dst, bytes, false);
+}

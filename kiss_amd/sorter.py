@@ -103,12 +103,30 @@ class Context:
                                                           SA.ctypes.data), "kiss_hip_ctx_suffix_sort_dna_u32", self._ctx)
         return SA
 
+    def suffix_sort_host(self, S, SA, k=256, algo=_lib.ALGO_PARALLEL_SORTING):
+        """host S (uint8 numpy, n) -> host SA (uint32 numpy, n+1, caller-allocated, e.g. page-locked): the reference's
+        timed region; kiss_hip_ctx_suffix_sort_dna_u32 without the allocation `suffix_sort` does."""
+        assert S.dtype == np.uint8 and SA.dtype == np.uint32 and SA.size == S.size + 1
+        assert S.flags["C_CONTIGUOUS"] and SA.flags["C_CONTIGUOUS"]
+        _check(self._lib.kiss_hip_ctx_suffix_sort_dna_u32(self._ctx, S.ctypes.data, S.size, int(k) & 0xFFFFFFFF, int(algo),
+                                                          SA.ctypes.data), "kiss_hip_ctx_suffix_sort_dna_u32", self._ctx)
+        return SA
+
     def suffix_sort_dev(self, d_S_ptr, n, d_SA_ptr, k=256, algo=_lib.ALGO_PARALLEL_SORTING, stream=None):
         """Device-resident form: raw device pointers (e.g. torch tensor .data_ptr())."""
         _check(self._lib.kiss_hip_ctx_suffix_sort_dna_u32_dev(self._ctx, ctypes.c_void_p(d_S_ptr), int(n),
                                                               int(k) & 0xFFFFFFFF, int(algo), ctypes.c_void_p(d_SA_ptr),
                                                               ctypes.c_void_p(stream or 0)),
                "kiss_hip_ctx_suffix_sort_dna_u32_dev", self._ctx)
+
+    def verify_sa_dev(self, d_S_ptr, n, d_SA_ptr, k=256, stream=None):
+        """device-side check of a suffix array (kiss_hip_ctx_verify_sa_dev) -> report dict; raises nothing on a bad SA,
+        read report["ok"]"""
+        rep = _lib.VerifyReport()
+        _check(self._lib.kiss_hip_ctx_verify_sa_dev(self._ctx, ctypes.c_void_p(d_S_ptr), int(n), int(k) & 0xFFFFFFFF,
+                                                    ctypes.c_void_p(d_SA_ptr), ctypes.byref(rep),
+                                                    ctypes.c_void_p(stream or 0)), "kiss_hip_ctx_verify_sa_dev", self._ctx)
+        return rep.as_dict()
 
     def stage_outputs(self):
         """(ascending LMS positions, k-ordered LMS positions, counts[12]) of the last sort."""
@@ -120,6 +138,21 @@ class Context:
         _check(self._lib.kiss_hip_ctx_get_stage_outputs(self._ctx, asc.ctypes.data, srt.ctypes.data,
                                                         counts.ctypes.data), "kiss_hip_ctx_get_stage_outputs", self._ctx)
         return asc, srt, counts
+
+
+FNV1A64_SEED = 0xcbf29ce484222325
+
+
+def fnv1a64(buf, seed=FNV1A64_SEED):
+    """FNV-1a-64 over the bytes of a numpy array (host helper of the library, no device)"""
+    a = np.ascontiguousarray(buf)
+    return int(_lib.load().kiss_hip_fnv1a64_host(a.ctypes.data, a.nbytes, seed))
+
+
+def sa_digest(SA):
+    """the order-sensitive digest kiss_hip_ctx_verify_sa_dev reports, recomputed on the host"""
+    a = np.ascontiguousarray(SA, dtype=np.uint32)
+    return int(_lib.load().kiss_hip_sa_digest_host(a.ctypes.data, a.size))
 
 
 class KISS1Sorter:
@@ -154,5 +187,6 @@ def suffix_array_bytes(data, device=0):
 
 
 class KISS2Sorter(KISS1Sorter):
-    """PREFIX_DOUBLING (kiss2_sorter.hpp:8-50); defined for k >= n (exact suffix array) only."""
+    """PREFIX_DOUBLING (kiss2_sorter.hpp:8-50): exact suffix array for k >= n; for a bounded k the deterministic
+    k-ordered array of KISS1 (the reference's own bounded-k KISS2 result depends on its thread count)."""
     algo = _lib.ALGO_PREFIX_DOUBLING

@@ -47,10 +47,26 @@ def test_fails_loudly_without_device():
     assert raised
 
 
-def test_stats_struct_matches_header():
-    # sizeof(kiss_hip_stats) computed from the header's field list
-    assert ctypes.sizeof(_lib.Stats) == 8 + 8 + 4 + 4 + 4 + 4 + 8 + 8 + 8 + 6 * 4 + 16 * 4 + 4 + 16 * 8 + 16 * 8 or \
-        ctypes.sizeof(_lib.Stats) % 8 == 0
+def _sizeof_from_header(struct_name):
+    """compiles a one-line C program against include/kiss_hip.h and returns sizeof(struct) as the C compiler sees it"""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include "kiss_hip.h"\nint main(void){printf("%%zu", sizeof(%s));return 0;}\n'
+                             % struct_name)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        return int(subprocess.check_output([exe]).decode())
+
+
+def test_ctypes_structs_match_the_header():
+    # the ctypes mirrors must have exactly the size the C compiler gives the header's structs
+    assert ctypes.sizeof(_lib.Stats) == _sizeof_from_header("kiss_hip_stats")
+    assert ctypes.sizeof(_lib.VerifyReport) == _sizeof_from_header("kiss_hip_verify_report")
+    assert ctypes.sizeof(_lib.FmiView) == _sizeof_from_header("kiss_hip_fmi_view")
+    # and the field the Python side reads last sits where the header puts it
+    assert _lib.Stats.ms_refine.offset == ctypes.sizeof(_lib.Stats) - 16
 
 
 def test_cpp_host_facade_compiles_and_links(tmp_path):

@@ -27,9 +27,15 @@ def run_bench(*extra):
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
-    out = run_bench("--cpu-sample", "1000000")
+    out = run_bench("--cpu-sample", "1000000", "--fm-text-len", "2000000", "--fm-queries", "20000")
     for k in REQUIRED:
         assert k in out, k
+    # the run checks itself: the last SA verified on the device, host S -> host SA timed, FM queries/s with parity
+    assert out["verified"] is True and out["verify"]["order_violations"] == 0 and len(out["sa_fnv1a64"]) == 16
+    e = out["end_to_end"]
+    assert e["pinned"]["ms"] > 0 and e["pageable"]["ms"] > 0 and e["pcie_h2d_GBps"] > 1 and e["floor_ms"] > 0
+    fq = out["fm_query"]
+    assert fq["value"] > 0 and fq["parity_vs_oracle_all_patterns"] is True and fq["roofline"]["bound"] == "infinity_cache"
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "bases/s"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["vs_baseline"] is None and out["dtype"] == "u8"
     assert "workload" in out["config"] and "model" not in out["config"]
@@ -43,5 +49,5 @@ def test_bench_single_gpu_line():
 @pytest.mark.gpu
 def test_bench_sharded_path_on_one_rank():
     out = run_bench("--cpu-sample", "0", "--force-sharded", "--no-profile")
-    assert out["scaling"] == "strong" and out["value"] > 0
+    assert out["scaling"] == "strong" and out["value"] > 0 and out["verified"] is True and out["n_gpus"] == 1
     assert "sharded_error" not in out["config"]

@@ -223,9 +223,8 @@ def test_error_codes(ctx):
     with pytest.raises(kiss_amd.KissHipError) as e:      # unknown algorithm
         ctx.suffix_sort(S, 256, algo=7)
     assert e.value.status == _lib.KISS_HIP_E_INVALID
-    with pytest.raises(kiss_amd.KissHipError) as e:      # KISS2 with bounded k is not a function of its input
-        ctx.suffix_sort(S, 256, algo=1)
-    assert e.value.status == -5                           # KISS_HIP_E_UNSUPPORTED
+    # KISS2 with a bounded k (the CLI's `-s PREFIX_DOUBLING` with the default k): accepted, the k-ordered SA of KISS1
+    assert np.array_equal(ctx.suffix_sort(S, 256, algo=1), ctx.suffix_sort(S, 256, algo=0))
     SA = np.empty(4, np.uint32)
     assert lib.kiss_hip_suffix_sort_dna_u32(None, 3, 256, 0, SA.ctypes.data, 0) == _lib.KISS_HIP_E_INVALID
     assert lib.kiss_hip_suffix_sort_dna_u32(S.ctypes.data, 3, 256, 0, None, 0) == _lib.KISS_HIP_E_INVALID
@@ -337,3 +336,32 @@ def test_two_contexts_concurrently(oracle):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("k", [130_000, 200_000, 999_000])
+def test_bounded_k_with_many_near_end_suffixes(oracle, k):
+    # k in the hundred thousands (but < n): more than 65 536 LMS suffixes have fewer than D bases left and follow the
+    # comparator's scalar tail (kiss1_core.hpp:120-134).  Round 1 refused these; the reference takes any k.
+    import kiss_amd
+    S = gen.genome_like(1_000_000, 17)
+    with kiss_amd.Context(max_n=S.size, device=0) as c:
+        sa = check_parity(c, oracle, S, k)
+        assert c.stats()["near_end"] > 4096  # the merge-sort form ran
+        assert sa[0] == S.size
+
+
+def test_near_end_merge_form_equals_pairwise_form(ctx, oracle, monkeypatch):
+    # the same inputs through both near-end forms (the switch is read per call)
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 4, 30_000, dtype=np.uint8)
+    cases = [np.concatenate([base, base[5000:5000 + cut]]) for cut in (10, 124, 125, 126, 256, 300, 375, 376, 500)]
+    cases += [gen.periodic(20_000, p, 3 + p, mutations=4) for p in (1, 2, 3, 7, 37, 400)]
+    cases += [np.tile(np.array([0, 1], np.uint8), 2000), gen.iid(5, 1), gen.iid(300, 2)]
+    for S in cases:
+        for k in (32, 256, 1000):
+            monkeypatch.setenv("KISS_HIP_NEAR_MERGE_MIN", "1")
+            a = check_parity(ctx, oracle, S, k)
+            monkeypatch.setenv("KISS_HIP_NEAR_MERGE_MIN", "1000000000")
+            b = check_parity(ctx, oracle, S, k)
+            assert np.array_equal(a, b)
+    monkeypatch.delenv("KISS_HIP_NEAR_MERGE_MIN")
