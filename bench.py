@@ -282,16 +282,31 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
     return out
 
 
-def cpu_baseline(S_host_sample, k):
-    """Times the CPU oracle (a port: plain C restatement of the reference algorithm, OpenMP only in the
-    per-bucket LMS sort) on a bounded sample.  Reported baseline, not the optimisation target."""
-    from tests import oracle_binding
+def cpu_baseline(S_host_sample, k, threads=24):
+    """Times the CPU path on a bounded sample, on the GPU box's host cores.  Reported baseline, not the optimisation
+    target.  Preferred: oracle/_ref/libkiss_ref.so ("reference": the reference's OWN get_lms, PackedDNAString loads,
+    put_lms_suffix and induced_sort compiled unmodified from its sources, with its OpenMP block scheduling, at the
+    README's 24 threads; the one stage that lives in kiss1_core.hpp -- bucket scatter + per-bucket std::sort, which needs
+    spdlog to compile -- is the restated kref_lms_sort of oracle/ref_driver.cpp, OpenMP over buckets like the
+    reference).  Fallback where the prebuilt library did not travel: the plain C oracle ("port")."""
+    from tests import oracle_binding, ref_binding
+    n = S_host_sample.size
+    if ref_binding.available() and os.path.exists(ref_binding.LIB):
+        ref = ref_binding.load()
+        T = max(1, min(threads, ref.max_threads()))
+        t0 = time.time()
+        ref.suffix_sort(S_host_sample, k, T=T)
+        dt = time.time() - t0
+        return {"value": n / dt, "unit": "bases/s", "cores": T, "kind": "reference",
+                "sample": "first %d bases of the same synthetic text, k=%d, %.1f s; oracle/_ref: reference get_lms + "
+                          "put_lms_suffix + induced_sort compiled unmodified, LMS sort (kiss1_core.hpp:41-144, needs "
+                          "spdlog) restated in oracle/ref_driver.cpp" % (n, k, dt)}
     orc = oracle_binding.load()
     t0 = time.time()
     orc.suffix_sort(S_host_sample, k)
     dt = time.time() - t0
-    return {"value": S_host_sample.size / dt, "unit": "bases/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "first %d bases of the same synthetic text, k=%d, %.1f s" % (S_host_sample.size, k, dt)}
+    return {"value": n / dt, "unit": "bases/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "first %d bases of the same synthetic text, k=%d, %.1f s (oracle/_ref not present)" % (n, k, dt)}
 
 
 EXIT_TOO_FEW_DEVICES = 3  # a rank found fewer visible GPUs than --gpus: never retried, never a silent 1-GPU number
@@ -390,8 +405,8 @@ def main():
                     help="prefix_doubling: exact order (k is ignored), bounded phase + rank doubling")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
-    ap.add_argument("--cpu-sample", type=int, default=500_000_000,
-                    help="bases of the CPU baseline sample (0 = skip); 5e8 bases = ~15-20 s of oracle time on the GPU box")
+    ap.add_argument("--cpu-sample", type=int, default=1_500_000_000,
+                    help="bases of the CPU baseline sample (0 = skip); 1.5e9 bases = ~15 s of oracle/_ref time at 24 threads")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: 'sharded' = ONE text, LMS sort sharded by key range over the ranks with an RCCL "
