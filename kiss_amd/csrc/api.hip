@@ -39,6 +39,53 @@ void ktimer_collect(kiss_hip_ctx *ctx)
     ctx->ev_used = 0;
 }
 
+// ---- low-latency read-back ------------------------------------------------------------------------------
+// A refinement round or an induction pass ends with the host reading a few counters to size the next launches
+// (about a hundred times per sort).  hipMemcpyAsync + hipStreamSynchronize leaves the GPU idle for 40-60 us each time;
+// a one-wave kernel that stores the words into coherent host memory followed by a sequence number, with the host
+// spinning on that number, brings the hand-over down to the PCIe write + the next launch.
+__global__ void k_publish(const uint32_t *__restrict__ src, uint32_t nwords, uint32_t *host_dst, uint32_t seq)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < nwords) __hip_atomic_store(&host_dst[t], src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system(); // the data words are visible to the host before the sequence number is
+    if (t == 0) __hip_atomic_store(&host_dst[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
+{
+    if (nwords > 16) return KINTERNAL();
+    if (ctx->pub_mode < 0) {
+        const char *e = getenv("KISS_HIP_SYNC_READBACK");
+        ctx->pub_mode = (e && atoi(e) != 0) || !ctx->h_pub || !ctx->d_pub ? 0 : 1;
+    }
+    if (ctx->pub_mode == 0) {
+        KCHECK(hipMemcpyAsync(ctx->h_pinned, d_src, nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        return KISS_HIP_OK;
+    }
+    const uint32_t seq = ++ctx->pub_seq ? ctx->pub_seq : ++ctx->pub_seq; // never 0: the buffer starts zeroed
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t *)d_src, nwords, ctx->d_pub, seq);
+    KCHECK(hipGetLastError());
+    volatile uint32_t *flag = ctx->h_pub + 16;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0xFFFF) {
+            // a kernel that faulted never publishes: after 5 s ask the runtime what happened instead of spinning on
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (s > 5.0) {
+                KCHECK(hipStreamSynchronize(ctx->stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return KINTERNAL();
+                break;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < nwords; i++) ctx->h_pinned[i] = ctx->h_pub[i];
+    return KISS_HIP_OK;
+}
+
 namespace {
 
 template <typename T>
@@ -102,6 +149,7 @@ void free_all(kiss_hip_ctx *ctx)
     if (ctx->io_SA) (void)hipFree(ctx->io_SA);
     kiss_xfer_free(ctx);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_pub) (void)hipHostFree(ctx->h_pub);
     for (auto &e : ctx->ev_pool) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -383,6 +431,18 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
             break;
         }
         ctx->h_pinned = reinterpret_cast<uint32_t *>(hp);
+        // coherent (fine-grained) host buffer of kiss_readback; if the platform refuses it the memcpy form is used
+        void *pub = nullptr, *dpub = nullptr;
+        if (hipHostMalloc(&pub, 32 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+            std::memset(pub, 0, 32 * sizeof(uint32_t));
+            if (hipHostGetDevicePointer(&dpub, pub, 0) == hipSuccess) {
+                ctx->h_pub = reinterpret_cast<uint32_t *>(pub);
+                ctx->d_pub = reinterpret_cast<uint32_t *>(dpub);
+            } else {
+                (void)hipHostFree(pub);
+            }
+        }
+        (void)hipGetLastError();
     } while (0);
     if (rc != KISS_HIP_OK) {
         free_all(ctx);

@@ -376,8 +376,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_scan_u32(ctx, ctx->tile_cnt, ctx->tile_cnt, tiles));
-    KCHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_counts, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_readback(ctx, ctx->d_counts, 16));
     for (int i = 0; i < 12; i++) ctx->counts[i] = ctx->h_pinned[i];
     uint64_t m = (uint64_t)ctx->h_pinned[8] + ctx->h_pinned[9] + ctx->h_pinned[10] + ctx->h_pinned[11];
     ctx->m = m;

@@ -381,8 +381,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
                                sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small);
             KCHECK(hipGetLastError());
         }
-        KCHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        KCHECK(hipStreamSynchronize(ctx->stream));
+        KTRY(kiss_readback(ctx, ctx->d_small, 5));
         for (int c = 0; c < 4; c++) tot[c] = ctx->h_pinned[c];
         *chain_done = true;
     } else {
@@ -401,8 +400,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
                                srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small);
             KCHECK(hipGetLastError());
         }
-        KCHECK(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        KCHECK(hipStreamSynchronize(ctx->stream));
+        KTRY(kiss_readback(ctx, ctx->d_small, 4));
         for (int c = 0; c < 4; c++) tot[c] = ctx->h_pinned[c];
     }
     if (getenv("KISS_HIP_DEBUG"))
@@ -604,8 +602,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         }
         KTRY(kiss_scan_u32(ctx, run, ex, N));
         hipLaunchKernelGGL(k_chain_total, dim3(1), dim3(64), 0, ctx->stream, run, ex, N, counters);
-        KCHECK(hipMemcpyAsync(ctx->h_pinned, counters, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        KCHECK(hipStreamSynchronize(ctx->stream));
+        KTRY(kiss_readback(ctx, counters, 6));
         uint32_t cnt[4];
         for (int x = 0; x < 4; x++) cnt[x] = ctx->h_pinned[x];
         const uint64_t ncap = ctx->h_pinned[4];

@@ -83,6 +83,12 @@ struct kiss_hip_ctx {
     uint64_t ind_tiles_cap = 0;
     uint32_t *d_small = nullptr;   // small scratch (64 u32) for single-workgroup kernels
     uint32_t *h_pinned = nullptr;  // 64 u32 pinned host scratch
+    // low-latency read-back of a few words (api.hip: kiss_readback): a one-wave kernel stores them into this coherent
+    // host buffer and then a sequence number; the host spins on the sequence number instead of synchronising the stream
+    uint32_t *h_pub = nullptr;     // 32 u32: [0,16) data, [16] sequence number
+    uint32_t *d_pub = nullptr;     // device-side address of h_pub
+    uint32_t pub_seq = 0;
+    int pub_mode = -1;             // -1 undecided, 0 = memcpy + stream synchronise, 1 = publish + spin
     // PREFIX_DOUBLING: (position, index) pairs of the binned inverse-suffix-array build (isa.hip), allocated on first use
     uint64_t *pairs1 = nullptr, *pairs2 = nullptr;
     uint64_t pairs_cap = 0;
@@ -136,6 +142,9 @@ int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);
 // classification: fills ctx->lms_pos, ctx->keyA (first 32 bases of each LMS), ctx->counts, ctx->m, ctx->m_far
 // only LMS suffixes / histogram contributions of text positions in [win_lo, win_hi) are produced (sharded runs)
 int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*/, uint64_t win_lo, uint64_t win_hi);
+// copies nwords (<= 16) 32-bit words from device memory to ctx->h_pinned[0 .. nwords) after everything queued on the
+// ctx stream so far has finished; returns when they are there (the per-round / per-pass control values of the drivers)
+int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords);
 // exclusive scans (in place allowed: out may equal in)
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count);
 int kiss_scan_u64(kiss_hip_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t count);

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -290,6 +291,132 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__
     const uint32_t i = bidx[c];
     okey[i] = skey[c];
     opos[i] = spos[c];
+}
+
+// ---- pivot rounds: a big segment against its middle member, to the full depth -------------------------------------
+// What is still tied in big segments after two rounds is long tandem arrays (and the odd high-copy repeat).  Their
+// members stay tied round after round -- eleven more 32-base rounds of ~40 launches and an 8 + 2-pass radix sort each at
+// D = 375 -- although one comparison says almost everything: every member is compared with ONE reference string (the
+// segment's consensus, see k_pivot_lcp) from the current depth to the full depth D, giving
+//     side = member < reference | equal through D | member > reference,   d = first differing base,   c = the member's base there.
+// Two members on the < side order by (d ascending, c); on the > side by (d descending, c); members equal through D
+// are final in their present (= text position) order.  One stable radix sort on (segment, side, d', c) -- 13 bits + the
+// segment id at k = 256 -- replaces the rounds.  Members with the same (side, d, c) are tied through off + d + 1 bases:
+// they form a new, much smaller segment that goes round again from the SAME depth `off` (so all survivors still share
+// one depth; the few bases they walk twice cost less than a per-segment depth would).  Progress: if every member of a
+// segment fell into the same (side, d, c) class, the three members the reference is made of would all carry base c at
+// d, and so would the reference -- so a segment always splits into at least two classes or retires as a whole.
+// Bounded depth only: in exact order (D unbounded) "equal through D" does not exist, the 32-base rounds run instead.
+// four aligned 32-base keys starting at base q (five independent word loads)
+__device__ __forceinline__ void keys128(const uint64_t *__restrict__ pk, uint64_t q, uint64_t k[4])
+{
+    const uint64_t *w = pk + (q >> 5);
+    const uint32_t sh = 2u * (uint32_t)(q & 31u);
+    uint64_t x[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) x[t] = w[t];
+#pragma unroll
+    for (int t = 0; t < 4; t++) k[t] = (x[t] << sh) | ((x[t + 1] >> 1) >> (63u - sh));
+}
+
+__device__ __forceinline__ uint64_t maj3(uint64_t a, uint64_t b, uint64_t c) { return (a & b) | (a & c) | (b & c); }
+
+// Key of a member: up to `slots` deviations from the reference, most significant first, then a "complete" bit:
+//     [side:2 | d':dbits | c:2] x slots ... [complete:1]          in the TOP bits of a 64-bit word
+// side 0: the member's base is smaller than the reference's at d (d' = d: the earlier the deviation, the smaller the
+// member), side 2: larger (d' = rem - 1 - d: the earlier, the larger), side 1: no further deviation through the depth
+// (terminator; the walk is complete and the key says everything the comparator can see).  Members that are equal up to
+// and including a deviation keep following the same argument from the next base on, so the slots compare
+// lexicographically.  After a substitution a tandem array is back in phase with its consensus, so the next slot holds
+// the member's next mutation: one round looks `slots` mutations deep.
+__global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__restrict__ pk,
+                                                         const uint32_t *__restrict__ bpos,
+                                                         const uint32_t *__restrict__ bseg,
+                                                         const uint32_t *__restrict__ bsegstart, uint64_t nbig,
+                                                         uint64_t off, uint64_t depth, int dbits, int slots,
+                                                         uint64_t *__restrict__ keyout)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= nbig) return;
+    const uint32_t sid = bseg[i];
+    const uint32_t a = bsegstart[sid], b = bsegstart[sid + 1], len = b - a;
+    // The reference the members are compared with may be ANY fixed string (the order argument only needs it to be the
+    // same for the whole segment).  A real member carries its own mutations, and everything that follows the consensus
+    // up to that member's first mutation would land in one class.  The bitwise majority of three members is the
+    // consensus wherever at most one of them is mutated: members of a tandem array then deviate from the reference at
+    // their OWN mutations.
+    const uint64_t p = (uint64_t)bpos[i] + off;
+    // (5/17, 9/17, 13/17 rather than the quarters: arrays of equal length, e.g. telomeres, put the quarters of a
+    //  segment exactly at array ends, where the members stop following the consensus)
+    const uint64_t q1 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 5) / 17)] + off,
+                   q2 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 9) / 17)] + off,
+                   q3 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 13) / 17)] + off;
+    const uint64_t rem = depth - off; // all of them are far suffixes: position + rem lies inside the text
+    const int slotbits = dbits + 4;
+    uint64_t key = 0;
+    int used = 0;
+    bool complete = false;
+    auto take = [&](uint64_t kx, uint64_t kr, uint64_t base0) { // deviations inside one 32-base word, in text order
+        uint64_t diff = kx ^ kr;
+        diff = (diff | (diff >> 1)) & 0x5555555555555555ull; // one flag per base (its low bit)
+        while (diff && used < slots) {
+            const uint32_t lz = (uint32_t)__clzll((long long)diff) >> 1; // base index inside the word
+            const uint32_t sh = 62u - 2u * lz;
+            const uint64_t cx = (kx >> sh) & 3ull, cr = (kr >> sh) & 3ull;
+            const uint64_t d = base0 + lz;
+            const uint64_t side = cx < cr ? 0ull : 2ull;
+            const uint64_t dk = side == 0 ? d : rem - 1 - d;
+            key = (key << slotbits) | (side << (dbits + 2)) | (dk << 2) | cx;
+            used++;
+            diff &= ~(1ull << sh);
+        }
+    };
+    uint64_t done = 0;
+    while (done < rem && used < slots) {
+        if (rem - done >= 128) { // four words per step: the loads of one step are independent (one round trip to memory)
+            uint64_t kx[4], k1[4], k2[4], k3[4];
+            keys128(pk, p + done, kx);
+            keys128(pk, q1 + done, k1);
+            keys128(pk, q2 + done, k2);
+            keys128(pk, q3 + done, k3);
+#pragma unroll
+            for (int t = 0; t < 4; t++) take(kx[t], maj3(k1[t], k2[t], k3[t]), done + 32u * (uint32_t)t);
+            done += 128;
+            continue;
+        }
+        uint64_t ki = kiss_key32(pk, p + done);
+        uint64_t kr = maj3(kiss_key32(pk, q1 + done), kiss_key32(pk, q2 + done), kiss_key32(pk, q3 + done));
+        if (rem - done < 32) {
+            const uint64_t mask = ~0ull << (64 - 2 * (rem - done));
+            ki &= mask;
+            kr &= mask;
+        }
+        take(ki, kr, done);
+        done += 32;
+    }
+    if (used < slots) { // the walk reached the depth: terminator slot, the key is complete
+        key = (key << slotbits) | (1ull << (dbits + 2));
+        used++;
+        complete = true;
+    }
+    key <<= (uint64_t)slotbits * (uint64_t)(slots - used); // unused slots: zeros (only behind a terminator)
+    key = (key << 1) | (complete ? 1ull : 0ull);
+    keyout[i] = key << (64 - (slots * slotbits + 1));
+}
+
+// boundaries of the new segments in the sorted list: one byte per item, 1 = (segment, key) differs from the predecessor's,
+// or the item's key is complete (it says everything the comparator sees: the item is final where the stable sort left it;
+// it and its successor both start a "segment", which makes it a singleton for the compaction)
+__global__ __launch_bounds__(LS_THREADS) void k_pivot_heads(const uint64_t *__restrict__ key,
+                                                           const uint32_t *__restrict__ seg, uint64_t nbig,
+                                                           int complete_bit, uint8_t *__restrict__ heads)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= nbig) return;
+    const uint64_t k = key[i];
+    uint8_t h = 1;
+    if (i > 0 && !((k >> complete_bit) & 1ull) && seg[i] == seg[i - 1] && key[i - 1] == k) h = 0;
+    heads[i] = h;
 }
 
 
@@ -726,8 +853,7 @@ int fc_count(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, uint64
 
 int fc_read_total(kiss_hip_ctx *ctx, const uint64_t *d_total, uint64_t *tot)
 {
-    KCHECK(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_readback(ctx, d_total, 2));
     std::memcpy(tot, ctx->h_pinned, sizeof(uint64_t));
     return KISS_HIP_OK;
 }
@@ -799,8 +925,7 @@ int bits_for(uint64_t count)
 
 int read_u64(kiss_hip_ctx *ctx, const void *dptr, uint64_t *out)
 {
-    KCHECK(hipMemcpyAsync(ctx->h_pinned, dptr, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    KTRY(kiss_readback(ctx, dptr, 2));
     std::memcpy(out, ctx->h_pinned, sizeof(uint64_t));
     return KISS_HIP_OK;
 }
@@ -824,6 +949,13 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const bool pivot_on = getenv("KISS_HIP_NO_PIVOT_ROUNDS") == nullptr; // test / A-B hook: 32-base rounds only
+    const bool pivot_r1 = getenv("KISS_HIP_PIVOT_FROM_ROUND1") != nullptr; // experiment: pivot rounds from the first refinement round
+    int pivot_slots = 3; // deviations recorded per member and round (tuning hook: 1 .. 4)
+    if (const char *e = getenv("KISS_HIP_PIVOT_SLOTS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) pivot_slots = v;
+    }
     uint32_t small_seg = SMALL_SEG;
     if (const char *e = getenv("KISS_HIP_SMALL_SEG")) { // tuning hook
         int v = atoi(e);
@@ -941,6 +1073,71 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         // from their pivot at chm13 size): the split only pays from the second round on, when what is left is the
         // long tandem arrays
         if (off == ROUND0_BASES) NE = nullptr;
+        // ---- pivot round (bounded depth, from the second refinement round on): see k_pivot_lcp
+        if (depth && (off > ROUND0_BASES || pivot_r1) && pivot_on) {
+            const int dbits = bits_for(depth - off);          // d < depth - off
+            int slots = 63 / (dbits + 4);                     // deviations per key: [side 2 | d | base 2] each + 1 bit
+            if (slots > pivot_slots) slots = pivot_slots;
+            const int kbits = slots * (dbits + 4) + 1;
+            const int key_lo = 64 - 8 * ((kbits + 7) / 8);
+            {
+                KTimer t(ctx, KISS_HIP_K_SEGRANK, nbig);
+                hipLaunchKernelGGL(k_pivot_lcp, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->pk, ctx->bposA, ctx->bsegA, bss, nbig,
+                                   off, depth, dbits, slots, ctx->bkeyB);
+                KCHECK(hipGetLastError());
+            }
+            if (const char *dump = getenv("KISS_HIP_DUMP_PIVOT")) { // debugging aid: the inputs and keys of this pivot round
+                std::vector<uint32_t> hp(nbig), hs(nbig), hss(nbigseg + 1);
+                std::vector<uint64_t> hk(nbig);
+                KCHECK(hipStreamSynchronize(ctx->stream));
+                KCHECK(hipMemcpy(hp.data(), ctx->bposA, nbig * 4, hipMemcpyDeviceToHost));
+                KCHECK(hipMemcpy(hs.data(), ctx->bsegA, nbig * 4, hipMemcpyDeviceToHost));
+                KCHECK(hipMemcpy(hss.data(), bss, (nbigseg + 1) * 4, hipMemcpyDeviceToHost));
+                KCHECK(hipMemcpy(hk.data(), ctx->bkeyB, nbig * 8, hipMemcpyDeviceToHost));
+                char name[512];
+                snprintf(name, sizeof name, "%s.%u", dump, ctx->stats.lms_rounds);
+                if (FILE *f = fopen(name, "wb")) {
+                    const uint64_t hdr[6] = {nbig, nbigseg, off, depth, (uint64_t)dbits, (uint64_t)slots};
+                    fwrite(hdr, 8, 6, f);
+                    fwrite(hp.data(), 4, nbig, f);
+                    fwrite(hs.data(), 4, nbig, f);
+                    fwrite(hss.data(), 4, nbigseg + 1, f);
+                    fwrite(hk.data(), 8, nbig, f);
+                    fclose(f);
+                }
+            }
+            RadixBufs pb;
+            pb.key[0] = ctx->bkeyB;
+            pb.key[1] = ctx->keyB; // free since the round-0 compaction (K1 is keyA)
+            pb.pos[0] = ctx->bposA;
+            pb.pos[1] = ctx->bposB;
+            pb.seg[0] = ctx->bsegA;
+            pb.seg[1] = ctx->bsegB;
+            int pres = 0;
+            const int sbits = bits_for(nbigseg);
+            KTRY(kiss_radix_sort(ctx, pb, nbig, key_lo, sbits, &pres));
+            // a single segment has no segment digits: the sort then leaves the segment column alone (all the same id)
+            const uint32_t *sseg = sbits ? pb.seg[pres] : ctx->bsegA;
+            uint8_t *heads = reinterpret_cast<uint8_t *>(ctx->segB); // scratch of the 32-base form, free here
+            {
+                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+                hipLaunchKernelGGL(k_pivot_heads, dim3(bgrid), dim3(T), 0, ctx->stream, pb.key[pres], sseg, nbig, 64 - kbits,
+                                   heads);
+                KCHECK(hipGetLastError());
+            }
+            KTRY((fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, nbig, 0, 0, d_total)));
+            KTRY(fc_read_total(ctx, d_total, &tot));
+            KTRY((fc_compact<FC_HEADS, true>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, pb.pos[pres], ctx->bslot,
+                                            nbig, 0, 0, Pc, Sc, Gc, SSc, ctx->lms_sorted_far, nullptr)));
+            ctx->stats.big_item_rounds += nbig;
+            count = tot >> 32;
+            nseg = tot & 0xFFFFFFFFull;
+            if (dbg)
+                fprintf(stderr, "[kiss_hip]   pivot round: %llu big-segment items in %llu segments -> %llu still tied in %llu "
+                                "segments (same depth)\n", (unsigned long long)nbig, (unsigned long long)nbigseg,
+                        (unsigned long long)count, (unsigned long long)nseg);
+            continue; // survivors are tied through off + d + 1 > off bases: the next round starts from the same depth
+        }
         RadixBufs bb;
         uint64_t *H1, *H2;
         if (NE) {
@@ -1004,7 +1201,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             ctx->stats.big_item_rounds += nbig;
             skey = bb.key[bres];
             spos = bb.pos[bres];
-            sseg = bb.seg[bres];
+            sseg = bits_for(nbigseg) ? bb.seg[bres] : ctx->bsegA; // one segment: no segment digits, the column did not move
         }
         KTRY((fused_compact<true, true>(ctx, skey, sseg, spos, ctx->bslot, nbig, 0, (int)last_round, Pc, Sc, Gc, SSc, d_total,
                                        &tot)));

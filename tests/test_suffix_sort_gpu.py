@@ -365,3 +365,35 @@ def test_near_end_merge_form_equals_pairwise_form(ctx, oracle, monkeypatch):
             b = check_parity(ctx, oracle, S, k)
             assert np.array_equal(a, b)
     monkeypatch.delenv("KISS_HIP_NEAR_MERGE_MIN")
+
+
+@pytest.mark.parametrize("k", [32, 256, 1000, 0xFFFFFFFF])
+def test_pivot_rounds_equal_32_base_rounds(oracle, monkeypatch, k):
+    # from the second refinement round on (bounded depth), a big segment is compared with its middle member to the full
+    # depth and sorted once on (side, first difference, base) -- k_pivot_lcp; KISS_HIP_NO_PIVOT_ROUNDS keeps the 32-base
+    # rounds.  Both against the oracle, on texts whose ties run deep: tandem arrays with sparse and dense mutations,
+    # unit lengths around the word and step sizes of the walk, and a high-copy repeat family.
+    import kiss_amd
+    rng = np.random.default_rng(5)
+    texts = [gen.genome_like(2_000_000, 41)]
+    for unit, muts in ((3, 300), (31, 200), (32, 200), (33, 200), (127, 150), (128, 150), (171, 400), (500, 100)):
+        texts.append(gen.periodic(400_000, unit, 100 + unit, mutations=muts))
+    fam = rng.integers(0, 4, 600, dtype=np.uint8)  # 3000 copies of one 600-base element, 3 % divergence
+    S = gen.iid(2_400_000, 9)
+    for c in range(3000):
+        cp = fam.copy()
+        m = rng.random(600) < 0.03
+        cp[m] = rng.integers(0, 4, int(m.sum()), dtype=np.uint8)
+        S[c * 800:c * 800 + 600] = cp
+    texts.append(S)
+    texts.append(gen.periodic(600_000, 7, 3, mutations=60_000))
+    with kiss_amd.Context(max_n=2_400_000, device=0) as c:
+        for S in texts:
+            want = oracle.suffix_sort(S, k)
+            monkeypatch.delenv("KISS_HIP_NO_PIVOT_ROUNDS", raising=False)
+            a = c.suffix_sort(S, k)
+            monkeypatch.setenv("KISS_HIP_NO_PIVOT_ROUNDS", "1")
+            b = c.suffix_sort(S, k)
+            monkeypatch.delenv("KISS_HIP_NO_PIVOT_ROUNDS")
+            assert np.array_equal(a, want), "pivot rounds"
+            assert np.array_equal(b, want), "32-base rounds"
