@@ -293,7 +293,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__
     opos[i] = spos[c];
 }
 
-// ---- pivot rounds: a big segment against its middle member, to the full depth -------------------------------------
+// ---- pivot rounds: the members of a big segment against one reference string, to the full depth -------------------------------------
 // What is still tied in big segments after two rounds is long tandem arrays (and the odd high-copy repeat).  Their
 // members stay tied round after round -- eleven more 32-base rounds of ~40 launches and an 8 + 2-pass radix sort each at
 // D = 375 -- although one comparison says almost everything: every member is compared with ONE reference string (the
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__rest
                                                          const uint32_t *__restrict__ bseg,
                                                          const uint32_t *__restrict__ bsegstart, uint64_t nbig,
                                                          uint64_t off, uint64_t depth, int dbits, int slots,
-                                                         uint64_t *__restrict__ keyout)
+                                                         uint64_t *__restrict__ keyout, int frac_den)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= nbig) return;
@@ -346,11 +346,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__rest
     // consensus wherever at most one of them is mutated: members of a tandem array then deviate from the reference at
     // their OWN mutations.
     const uint64_t p = (uint64_t)bpos[i] + off;
-    // (5/17, 9/17, 13/17 rather than the quarters: arrays of equal length, e.g. telomeres, put the quarters of a
-    //  segment exactly at array ends, where the members stop following the consensus)
-    const uint64_t q1 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 5) / 17)] + off,
-                   q2 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 9) / 17)] + off,
-                   q3 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * 13) / 17)] + off;
+    // Which three: the quarters of the segment in one round, 2/7 4/7 5/7 in the next, 3/11 5/11 8/11 in the third, and
+    // round again -- arrays of equal length (telomeres) put the quarters of a segment exactly at array ends, where
+    // members stop following the consensus; the next round then picks elsewhere.
+    const uint64_t f1 = frac_den == 4 ? 1 : (frac_den == 7 ? 2 : 3), f2 = frac_den == 4 ? 2 : (frac_den == 7 ? 4 : 5),
+                   f3 = frac_den == 4 ? 3 : (frac_den == 7 ? 5 : 8);
+    const uint64_t q1 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * f1) / (uint64_t)frac_den)] + off,
+                   q2 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * f2) / (uint64_t)frac_den)] + off,
+                   q3 = (uint64_t)bpos[a + (uint32_t)(((uint64_t)len * f3) / (uint64_t)frac_den)] + off;
     const uint64_t rem = depth - off; // all of them are far suffixes: position + rem lies inside the text
     const int slotbits = dbits + 4;
     uint64_t key = 0;
@@ -950,7 +953,10 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
     const bool pivot_on = getenv("KISS_HIP_NO_PIVOT_ROUNDS") == nullptr; // test / A-B hook: 32-base rounds only
-    const bool pivot_r1 = getenv("KISS_HIP_PIVOT_FROM_ROUND1") != nullptr; // experiment: pivot rounds from the first refinement round
+    // from the first refinement round on; KISS_HIP_PIVOT_FROM_ROUND2 keeps the first one in the 32-base form (A-B hook)
+    const bool pivot_r1 = getenv("KISS_HIP_PIVOT_FROM_ROUND2") == nullptr;
+    static const int pivot_den[3] = {4, 7, 11};
+    unsigned pivot_rounds_done = 0;
     int pivot_slots = 3; // deviations recorded per member and round (tuning hook: 1 .. 4)
     if (const char *e = getenv("KISS_HIP_PIVOT_SLOTS")) {
         const int v = atoi(e);
@@ -1002,7 +1008,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 
     // ------------------------------ rounds >= 1 ---------------------------------------------
     uint64_t off = ROUND0_BASES;
-    while (count > 0) {
+    bool first_refine = true; // the tied items' context words (in bslot) are only good for the first pass over them
+    for (;; first_refine = false) {
+        if (count == 0) break;
         if (depth && off >= depth) return KINTERNAL(); // the last round retires everything
         uint64_t rem = depth ? depth - off : 32;
         if (rem > 32) rem = 32;
@@ -1030,7 +1038,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
                                count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig,
-                               (have_tctx && off == ROUND0_BASES) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far);
+                               (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
@@ -1073,7 +1081,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         // from their pivot at chm13 size): the split only pays from the second round on, when what is left is the
         // long tandem arrays
         if (off == ROUND0_BASES) NE = nullptr;
-        // ---- pivot round (bounded depth, from the second refinement round on): see k_pivot_lcp
+        // ---- pivot round (bounded depth): see k_pivot_lcp
         if (depth && (off > ROUND0_BASES || pivot_r1) && pivot_on) {
             const int dbits = bits_for(depth - off);          // d < depth - off
             int slots = 63 / (dbits + 4);                     // deviations per key: [side 2 | d | base 2] each + 1 bit
@@ -1083,7 +1091,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             {
                 KTimer t(ctx, KISS_HIP_K_SEGRANK, nbig);
                 hipLaunchKernelGGL(k_pivot_lcp, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->pk, ctx->bposA, ctx->bsegA, bss, nbig,
-                                   off, depth, dbits, slots, ctx->bkeyB);
+                                   off, depth, dbits, slots, ctx->bkeyB, pivot_den[pivot_rounds_done % 3]);
+                pivot_rounds_done++;
                 KCHECK(hipGetLastError());
             }
             if (const char *dump = getenv("KISS_HIP_DUMP_PIVOT")) { // debugging aid: the inputs and keys of this pivot round

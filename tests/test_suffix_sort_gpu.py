@@ -395,5 +395,11 @@ def test_pivot_rounds_equal_32_base_rounds(oracle, monkeypatch, k):
             monkeypatch.setenv("KISS_HIP_NO_PIVOT_ROUNDS", "1")
             b = c.suffix_sort(S, k)
             monkeypatch.delenv("KISS_HIP_NO_PIVOT_ROUNDS")
+            monkeypatch.setenv("KISS_HIP_PIVOT_FROM_ROUND2", "1")
+            monkeypatch.setenv("KISS_HIP_PIVOT_SLOTS", "1")
+            d = c.suffix_sort(S, k)
+            monkeypatch.delenv("KISS_HIP_PIVOT_FROM_ROUND2")
+            monkeypatch.delenv("KISS_HIP_PIVOT_SLOTS")
             assert np.array_equal(a, want), "pivot rounds"
             assert np.array_equal(b, want), "32-base rounds"
+            assert np.array_equal(d, want), "pivot rounds from the second round on, one deviation per key"
