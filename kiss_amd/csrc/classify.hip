@@ -207,6 +207,45 @@ __global__ __launch_bounds__(1024) void k_tile_cin(uint32_t *__restrict__ tile_g
     }
 }
 
+// The same fold over 380 k tiles (chm13 size) by ONE workgroup is 0.7 ms of dependent loads; with a level in front it
+// is three launches of a few microseconds: chunks of TC_CHUNK tiles -> (G,P) per chunk -> k_tile_cin over the chunks ->
+// carry-ins inside every chunk.
+constexpr int TC_CHUNK = 16;
+__global__ __launch_bounds__(256) void k_tile_cin_chunks(const uint32_t *__restrict__ tile_gp, uint64_t tiles, uint64_t chunks,
+                                                         uint32_t *__restrict__ chunk_gp)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= chunks) return;
+    const uint64_t beg = c * TC_CHUNK, end = beg + TC_CHUNK < tiles ? beg + TC_CHUNK : tiles;
+    uint32_t a = 0, b = 1; // chunk carry-out for carry-in 0 / 1
+    for (uint64_t t = end; t > beg; t--) {
+        const uint32_t gp = tile_gp[t - 1];
+        const uint32_t g = gp & 1u, p = (gp >> 1) & 1u;
+        a = g | (p & a);
+        b = g | (p & b);
+    }
+    chunk_gp[c] = a | ((b & ~a) << 1);
+}
+
+__global__ __launch_bounds__(256) void k_tile_cin_apply(uint32_t *__restrict__ tile_gp, uint64_t tiles, uint64_t chunks,
+                                                        const uint32_t *__restrict__ chunk_cin)
+{
+    const uint64_t ch = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ch >= chunks) return;
+    const uint64_t beg = ch * TC_CHUNK, end = beg + TC_CHUNK < tiles ? beg + TC_CHUNK : tiles;
+    uint32_t gp[TC_CHUNK];
+#pragma unroll
+    for (int e = 0; e < TC_CHUNK; e++) gp[e] = beg + e < end ? tile_gp[beg + e] : 0u;
+    uint32_t c = chunk_cin[ch];
+#pragma unroll
+    for (int e = TC_CHUNK - 1; e >= 0; e--) {
+        if (beg + e < end) {
+            tile_gp[beg + e] = c;
+            c = (gp[e] & 1u) | (((gp[e] >> 1) & 1u) & c);
+        }
+    }
+}
+
 // ---- kernel 3/4: count (histograms + per-tile LMS count) and emit (positions + first keys) ------
 template <bool EMIT>
 __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restrict__ pk, uint64_t n, uint64_t words,
@@ -368,7 +407,16 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
         hipLaunchKernelGGL(k_tile_gp, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words,
                            ctx->tile_gp);
-        hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_gp, tiles);
+        if (tiles > 4096) { // two levels: per-chunk (G,P) in tile_cnt (free until the count pass writes it)
+            const uint64_t chunks = div_up(tiles, TC_CHUNK);
+            hipLaunchKernelGGL(k_tile_cin_chunks, dim3((unsigned)div_up(chunks, 256)), dim3(256), 0, ctx->stream, ctx->tile_gp,
+                               tiles, chunks, ctx->tile_cnt);
+            hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_cnt, chunks);
+            hipLaunchKernelGGL(k_tile_cin_apply, dim3((unsigned)div_up(chunks, 256)), dim3(256), 0, ctx->stream, ctx->tile_gp,
+                               tiles, chunks, ctx->tile_cnt);
+        } else {
+            hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_gp, tiles);
+        }
         unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
         hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
                            ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, (uint32_t *)nullptr,

@@ -700,17 +700,18 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
             cw[e] = 0;                  // tied so far: written when the item is finished, else gathered at placement
         }
     }
+    // out == nullptr: the positions already are where they belong (the last radix pass wrote them into the output list)
     if (valid == FC_ITEMS) {
 #pragma unroll
         for (int q = 0; q < FC_ITEMS / 4; q++) {
-            *reinterpret_cast<uint4 *>(out + i0 + 4 * q) = make_uint4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+            if (out) *reinterpret_cast<uint4 *>(out + i0 + 4 * q) = make_uint4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
             *reinterpret_cast<uint4 *>(octx + i0 + 4 * q) = make_uint4(cw[4 * q], cw[4 * q + 1], cw[4 * q + 2], cw[4 * q + 3]);
         }
     } else {
 #pragma unroll
         for (int e = 0; e < FC_ITEMS; e++)
             if ((uint32_t)e < valid) {
-                out[i0 + e] = p[e];
+                if (out) out[i0 + e] = p[e];
                 octx[i0 + e] = cw[e];
             }
     }
@@ -877,12 +878,13 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     else if (SRC == FC_KEY && !HAS_SLOT && !last_round && out && octx && !isa && cmp_shift >= 24)
     {
         hipLaunchKernelGGL(k_fc0_compact, dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, pos, count, cmp_shift, tex,
-                           npos, nslot, nseg, nsegstart, out, octx, nctx);
+                           npos, nslot, nseg, nsegstart, out == pos ? (uint32_t *)nullptr : out, octx, nctx);
         if (nctx_written) *nctx_written = nctx != nullptr;
     }
-    else
+    else // (without slots an item's slot is its index: out == pos means the list is in place already)
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
-                           pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart, out, isa, octx);
+                           pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
+                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -975,7 +977,10 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     rb.key[0] = ctx->keyA;
     rb.key[1] = ctx->keyB;
     rb.pos[0] = ctx->posA;
-    rb.pos[1] = ctx->posB;
+    // five passes: the result lands in buffer 1.  The sorted positions ARE the k-ordered list for every suffix that round 0
+    // makes unique, so the last pass writes them where they belong and the compaction below has nothing to copy.
+    static_assert(KISS_R0_PASSES % 2 == 1, "round-0 result must land in buffer 1");
+    rb.pos[1] = ctx->lms_sorted_far;
     rb.seg[0] = rb.seg[1] = nullptr;
     // depth >= 125 whenever bounded, so the first 20 bases always count in full
     const int r0_shift = 64 - 2 * ROUND0_BASES;

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(1024) void k_scan_single(T *__restrict__ data, uint
     }
 }
 
-template <typename T>
+// ONE_BLOCK: the whole input fits one block (count <= SCAN_BLOCK): no block sums, a single launch
+template <typename T, bool ONE_BLOCK>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T *in, T *out, uint64_t count,
                                                             const T *__restrict__ blocksums)
 {
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const T *in, T *out
         if (lane_id() == 63) wsum[r][wave] = inc[r];
     }
     __syncthreads();
-    T run = blocksums[blockIdx.x];
+    T run = ONE_BLOCK ? (T)0 : blocksums[blockIdx.x];
 #pragma unroll
     for (int r = 0; r < SCAN_ROWS; r++) {
         T pre = run;
@@ -163,9 +164,14 @@ int scan_impl(kiss_hip_ctx *ctx, const T *in, T *out, uint64_t count)
     if (nb > ctx->scan_tmp_cap) return KINTERNAL();
     T *bs = reinterpret_cast<T *>(ctx->scan_tmp);
     KTimer t(ctx, KISS_HIP_K_SCAN, count);
+    if (nb == 1) { // the per-pass control arrays of the drivers are mostly this small: one launch instead of three
+        hipLaunchKernelGGL((k_scan_final<T, true>), dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out, count, (const T *)nullptr);
+        KCHECK(hipGetLastError());
+        return KISS_HIP_OK;
+    }
     hipLaunchKernelGGL(k_scan_reduce<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, count, bs);
     hipLaunchKernelGGL(k_scan_single<T>, dim3(1), dim3(1024), 0, ctx->stream, bs, nb);
-    hipLaunchKernelGGL(k_scan_final<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, count, bs);
+    hipLaunchKernelGGL((k_scan_final<T, false>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, count, bs);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
