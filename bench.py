@@ -61,9 +61,13 @@ ALGO_BYTES = {
 MEASURED_TRAFFIC_PER_ALGO_BYTE = {"radix_scatter": 1.05}
 
 
-def gen_text_device(n, seed, device):
+def gen_text_device(n, seed, device, harsh=False):
     """Genome-like synthetic text on the GPU (torch ops only; deterministic for a given seed).
-    Same recipe as tests/gen.py::genome_like (SURVEY.md section 8(d))."""
+    Same recipe as tests/gen.py::genome_like (SURVEY.md section 8(d)).
+    harsh=True (bench.py --harsh; sensitivity runs, not the headline): satellite content closer to chm13's -- tandem
+    arrays covering 6 % of the text with lengths up to 30 Mb, a third of them alpha-satellite-like higher-order repeats
+    (12 monomers of 171 bases, 25 % apart from each other, the 2052-base unit repeated with 1 % divergence between
+    copies) -- instead of 3 % in arrays of at most 1 Mb."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -103,15 +107,24 @@ def gen_text_device(n, seed, device):
         seg = S[src:src + L].clone()
         S[dst:dst + L] = seg if cpu.random() < 0.5 else mutate(seg, 0.01)
         budget -= L
-    # tandem arrays: 3 %
-    budget = int(0.03 * n)
+    # tandem arrays: 3 % (harsh: 6 %, arrays up to 30 Mb, higher-order repeats)
+    budget = int((0.06 if harsh else 0.03) * n)
     units = [1, 2, 3, 4, 5, 6, 12, 171]
+    lmax = min(30_000_000, n // 8) if harsh else 1_000_000
     while budget > 0:
         u = units[int(cpu.integers(0, len(units)))]
-        L = int(min(1_000_000, max(200, 200 * (1.0 / max(1e-6, cpu.random())) ** 0.7)))
+        L = int(min(lmax, max(200, 200 * (1.0 / max(1e-6, cpu.random())) ** (1.0 if harsh else 0.7))))
         p = int(cpu.integers(0, n - L))
-        unit = torch.randint(0, 4, (u,), dtype=torch.uint8, device=device, generator=g)
-        S[p:p + L] = mutate(unit.repeat(L // u + 1)[:L], 0.005)
+        if harsh and cpu.random() < 1.0 / 3.0:  # higher-order repeat: 12 diverged monomers form the repeated unit
+            mono = torch.randint(0, 4, (171,), dtype=torch.uint8, device=device, generator=g)
+            unit = torch.cat([mutate(mono, 0.25) for _ in range(12)])
+            L = max(L, 20 * unit.numel())
+            L = min(L, n // 8)
+            p = int(cpu.integers(0, n - L))
+            S[p:p + L] = mutate(unit.repeat(L // unit.numel() + 1)[:L], 0.01)
+        else:
+            unit = torch.randint(0, 4, (u,), dtype=torch.uint8, device=device, generator=g)
+            S[p:p + L] = mutate(unit.repeat(L // u + 1)[:L], 0.005)
         budget -= L
     tel = torch.tensor([3, 3, 0, 2, 2, 2], dtype=torch.uint8, device=device).repeat(500)
     for c in range(24):
@@ -123,7 +136,7 @@ def gen_text_device(n, seed, device):
 FULL_SIZE_PINS = os.path.join(ROOT, "tests", "golden", "full_size_pins.json")
 
 
-def verify_leg(ctx, S, SA, n, k, seed, iid, algo, with_fnv):
+def verify_leg(ctx, S, SA, n, k, seed, iid, algo, with_fnv, harsh=False):
     """After the timed region: the LAST suffix array is checked on the device (kiss_hip_ctx_verify_sa_dev: permutation,
     SA[0] = n, the reference's own k-order test for every adjacent pair -- or, for k >= n, the linear-time proof of
     exactness) and hashed.  `sa_fnv1a64` (FNV-1a-64 over the u32-LE bytes, the hash the full-size oracle comparisons of
@@ -138,7 +151,7 @@ def verify_leg(ctx, S, SA, n, k, seed, iid, algo, with_fnv):
     out["verify"]["what"] = ("k >= n: proof that SA is THE suffix array" if rep["exact"] else
                              "SA[0] = n, permutation, substr(SA[i-1], k) <= substr(SA[i], k) for all i (tests/kiss.cpp:26-28)")
     key = None
-    if not iid and n == CHM13_N:
+    if not iid and not harsh and n == CHM13_N:
         key = "chm13size_seed%d_%s" % (seed, "exact" if k >= n else "k%d" % k)
     pins = {}
     if os.path.exists(FULL_SIZE_PINS):
@@ -405,6 +418,8 @@ def main():
                     help="prefix_doubling: exact order (k is ignored), bounded phase + rank doubling")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
+    ap.add_argument("--harsh", action="store_true",
+                    help="sensitivity run: 6 %% of the text in tandem arrays up to 30 Mb incl. higher-order repeats")
     ap.add_argument("--cpu-sample", type=int, default=1_500_000_000,
                     help="bases of the CPU baseline sample (0 = skip); 1.5e9 bases = ~15 s of oracle/_ref time at 24 threads")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
@@ -480,7 +495,7 @@ def main():
         g.manual_seed(seed)
         S = torch.randint(0, 4, (n,), dtype=torch.uint8, device=device, generator=g)
     else:
-        S = gen_text_device(n, seed, device)
+        S = gen_text_device(n, seed, device, harsh=args.harsh)
     SA = torch.empty(n + 1, dtype=torch.int32, device=device)  # u32 payload; torch has no uint32 arithmetic needs
     torch.cuda.synchronize()
 
@@ -550,7 +565,8 @@ def main():
             "config": {
                 "workload": "suffix_sort %s n=%d k=%d (stand-in for chm13v2.0.fa, BASELINE.json configs[1]); "
                             "%s; text resident in HBM, SA left in HBM"
-                            % ("i.i.d." if args.iid else "genome-like synthetic", n, k,
+                            % ("i.i.d." if args.iid else ("genome-like synthetic, HARSH satellite profile" if args.harsh
+                                                          else "genome-like synthetic"), n, k,
                                "PREFIX_DOUBLING (bounded phase + rank doubling)" if algo else "PARALLEL_SORTING"),
                 "n": n, "k": k, "seed": args.seed,
                 "parallelism": ("single GPU" if world == 1 else
@@ -558,6 +574,9 @@ def main():
                                  "list, gather of the sorted pieces, induction on rank 0)" % world) if sharded else
                                 "1 text per GPU (independent replicas)"),
                 "lms": last_stats["m"], "lms_rounds": last_stats["lms_rounds"],
+                "tied_after_round0_item_rounds": last_stats["sort_item_rounds"] - last_stats["m"],
+                "big_segment_item_rounds": last_stats["big_item_rounds"],
+                "workspace_bytes": ctx.workspace_bytes(),
                 "induce_passes": last_stats["induce_passes"],
                 "stage_ms_per_step": {s: v / args.steps for s, v in stage.items()},
             },
@@ -592,7 +611,8 @@ def main():
         out["path_roofline"] = {"algorithmic_bytes": path_bytes, "device_ms": 1e3 * dev_s,
                                 "achieved_GBps": path_bytes / dev_s / 1e9, "frac": path_bytes / dev_s / 1e9 / HBM_PEAK_GBS}
         if not args.no_verify:
-            out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid, algo, with_fnv=(world == 1 and not args.no_fnv)))
+            out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid, algo, with_fnv=(world == 1 and not args.no_fnv),
+                                  harsh=args.harsh))
         if world == 1 and not sharded and not args.no_e2e:
             out["end_to_end"] = end_to_end_leg(ctx, S, n, k, algo)
         if args.cpu_sample > 0 and world == 1:
