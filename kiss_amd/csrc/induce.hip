@@ -32,6 +32,12 @@ constexpr int IN_TILE = IN_THREADS * IN_ITEMS;   // 2048
 constexpr int SM_THREADS = 1024;
 constexpr uint64_t SMALL_MAX = 8192;             // rounds up to this size run in the single-workgroup kernel
 
+// word an induced item inherits: the parent's without its nearest base; the taint bit stays where it is
+__device__ __forceinline__ uint32_t child_ctx(uint32_t parent)
+{
+    return (KISS_CTX_WORD(parent) >> 2) | (parent & KISS_CTX_TAINT);
+}
+
 // class of a source item: 0..3 = append v-1 to bucket of that base, 4 = nothing to append
 __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
                                                int64_t phys, uint32_t emitmask, uint32_t *v_out, uint32_t *ctx_out)
@@ -39,12 +45,12 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
     uint32_t c = srcC[phys];
     uint32_t v = srcP[phys];
     *v_out = v;
-    if (c == KISS_EMPTY_CTX) {
+    if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) {
         if (v == 0) {
             *ctx_out = c;
             return 4u;
         }
-        c = kiss_load_ctx(pk, v);
+        c = kiss_load_ctx(pk, v) | (c & KISS_CTX_TAINT);
         srcC[phys] = c; // keep the refreshed word: the scatter pass (and the other sweep) reuse it
     }
     *ctx_out = c;
@@ -57,10 +63,10 @@ __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__
                                                     int64_t phys, uint32_t emitmask)
 {
     uint32_t c = srcC[phys];
-    if (c == KISS_EMPTY_CTX) {
+    if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) {
         const uint32_t v = srcP[phys];
         if (v == 0) return 4u;
-        c = kiss_load_ctx(pk, v);
+        c = kiss_load_ctx(pk, v) | (c & KISS_CTX_TAINT);
         srcC[phys] = c;
     }
     const uint32_t pc = c & 3u;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
             for (int e = 0; e < 4; e++) {
                 const uint32_t c = t[q].v[e];
                 uint32_t cls;
-                if (c == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0[q] + e, emitmask); // refresh path
+                if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0[q] + e, emitmask); // refresh path
                 else {
                     const uint32_t pc = c & 3u;
                     cls = ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         for (int e = 0; e < IN_ITEMS; e++) {
             const int a = dir > 0 ? e : IN_ITEMS - 1 - e; // place of item e inside the block
             uint32_t v = bp[a], c = bc[a], cls;
-            if (c == KISS_EMPTY_CTX) cls = item_class(pk, srcP, srcC, p0 + a, emitmask, &v, &c); // refresh path
+            if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) cls = item_class(pk, srcP, srcC, p0 + a, emitmask, &v, &c); // refresh path
             else {
                 const uint32_t pc = c & 3u;
                 cls = ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         if (cls < 4u) {
             const uint32_t li = coff[cls] + woff[cls] + (rr[j] & 0x0FFFFFFFu);
             stP[li] = vv[j] - 1u;
-            stC[li] = cc[j] >> 2;
+            stC[li] = child_ctx(cc[j]);
         }
     }
     __syncthreads();
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_induce_small(const uint64_t *__r
                 for (int w = 0; w < wave; w++) o += wtot[w][cls];
                 int64_t d = heads[cls] + (int64_t)dir * (int64_t)o;
                 SA[d] = v - 1u;
-                CTX[d] = cw >> 2;
+                CTX[d] = child_ctx(cw);
             }
             if (threadIdx.x < 4) {
                 uint32_t t = 0;
@@ -483,7 +489,8 @@ __device__ __forceinline__ uint32_t run_before(const uint64_t *__restrict__ pk, 
 
 // counters: [0..3] terminal items per class, [4] items whose run hit the cap
 __global__ __launch_bounds__(CH_THREADS) void k_chain_runs(const uint64_t *__restrict__ pk, const uint32_t *srcP,
-                                                          int64_t beg, uint64_t N, int dir, uint32_t c, uint32_t cap,
+                                                          const uint32_t *srcC, int64_t beg, uint64_t N, int dir, uint32_t c,
+                                                          uint32_t cap,
                                                           int rshift, uint32_t termmask, uint32_t *__restrict__ run,
                                                           uint64_t *__restrict__ tkey, uint32_t *__restrict__ tpos,
                                                           uint32_t *__restrict__ counters)
@@ -502,7 +509,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_runs(const uint64_t *__res
             uint32_t x = kiss_base(pk, u);
             if ((termmask >> x) & 1u) cls = x;
         }
-        tkey[i] = cls < 4u ? (((uint64_t)cls << 62) | ((uint64_t)r << rshift)) : ~0ull;
+        // bit 0: the taint of the item the terminal descends from (payload, below the sorted bits)
+        const uint64_t tn = srcC[beg + (int64_t)dir * (int64_t)i] >> 31;
+        tkey[i] = cls < 4u ? (((uint64_t)cls << 62) | ((uint64_t)r << rshift) | tn) : ~0ull;
         tpos[i] = u;
     }
 #pragma unroll
@@ -520,7 +529,8 @@ __global__ void k_chain_total(const uint32_t *__restrict__ run, const uint32_t *
     if (threadIdx.x == 0 && blockIdx.x == 0) counters[5] = ex[N - 1] + run[N - 1];
 }
 
-__global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *srcP, int64_t beg, int dir, uint64_t N,
+__global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *srcP, const uint32_t *srcC, int64_t beg, int dir,
+                                                            uint64_t N,
                                                             const uint32_t *__restrict__ ex, uint64_t E, int tshift,
                                                             uint64_t *__restrict__ key, uint32_t *__restrict__ pos)
 {
@@ -534,18 +544,20 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *src
         else hi = mid;
     }
     const uint32_t t = (uint32_t)(e - ex[lo]) + 1u;
-    key[e] = (uint64_t)t << tshift;
-    pos[e] = srcP[beg + (int64_t)dir * (int64_t)lo] - t;
+    const int64_t src = beg + (int64_t)dir * (int64_t)lo;
+    key[e] = ((uint64_t)t << tshift) | (uint64_t)(srcC[src] >> 31); // bit 0: the source item's taint (payload)
+    pos[e] = srcP[src] - t;
 }
 
 __global__ __launch_bounds__(CH_THREADS) void k_chain_write(const uint64_t *__restrict__ pk,
+                                                           const uint64_t *__restrict__ sorted_key,
                                                            const uint32_t *__restrict__ sorted_pos, uint64_t E,
                                                            int64_t dst, int dir, uint32_t *SA, uint32_t *CTX)
 {
     uint64_t e = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     if (e >= E) return;
     const uint32_t u = sorted_pos[e];
-    const uint32_t cw = kiss_load_ctx(pk, u);
+    const uint32_t cw = kiss_load_ctx(pk, u) | ((uint32_t)(sorted_key[e] & 1ull) << 31);
     const int64_t d = dst + (int64_t)dir * (int64_t)e;
     SA[d] = u;
     CTX[d] = cw;
@@ -557,6 +569,7 @@ struct TermDst {
 };
 
 __global__ __launch_bounds__(CH_THREADS) void k_chain_term_write(const uint64_t *__restrict__ pk,
+                                                                const uint64_t *__restrict__ sorted_tkey,
                                                                 const uint32_t *__restrict__ sorted_tpos, uint64_t T,
                                                                 TermDst td, int dir, uint32_t *SA, uint32_t *CTX)
 {
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_term_write(const uint64_t 
     const uint32_t u = sorted_tpos[j];
     const int64_t d = td.p[x] + (int64_t)dir * (int64_t)(j - td.off[x]);
     SA[d] = u;
-    CTX[d] = kiss_load_ctx(pk, u);
+    CTX[d] = kiss_load_ctx(pk, u) | ((uint32_t)(sorted_tkey[j] & 1ull) << 31);
 }
 
 int verify_part(kiss_hip_ctx *ctx, const uint32_t *SA, int64_t lo, int64_t hi, uint32_t c, uint64_t n, const char *what);
@@ -596,8 +609,8 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
             KTRY(kiss_zero_u32(ctx, counters, 8));
-            hipLaunchKernelGGL(k_chain_runs, dim3(grid), dim3(CH_THREADS), 0, ctx->stream, ctx->pk, sw.SA, beg, N, sw.dir,
-                               c, cap, rshift, termmask & ~(1u << c), run, tkey, tpos, counters);
+            hipLaunchKernelGGL(k_chain_runs, dim3(grid), dim3(CH_THREADS), 0, ctx->stream, ctx->pk, sw.SA, ctx->CTX, beg, N,
+                               sw.dir, c, cap, rshift, termmask & ~(1u << c), run, tkey, tpos, counters);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_scan_u32(ctx, run, ex, N));
@@ -616,7 +629,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         if (E > 0) {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
             hipLaunchKernelGGL(k_chain_expand, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
-                               sw.SA, beg, sw.dir, N, ex, E, tshift, ctx->keyA, ctx->posA);
+                               sw.SA, ctx->CTX, beg, sw.dir, N, ex, E, tshift, ctx->keyA, ctx->posA);
             KCHECK(hipGetLastError());
         }
         if (E > 0) {
@@ -630,7 +643,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             KTRY(kiss_radix_sort(ctx, rb, E, tshift, 0, &res)); // step index t sits in bits tshift..63
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
             hipLaunchKernelGGL(k_chain_write, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
-                               ctx->pk, rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
+                               ctx->pk, rb.key[res], rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
             KCHECK(hipGetLastError());
             if (getenv("KISS_HIP_VERIFY")) {
                 int64_t lo = sw.dir > 0 ? dst : dst - (int64_t)E + 1, hi = sw.dir > 0 ? dst + (int64_t)E : dst + 1;
@@ -658,7 +671,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             td.off[4] = o;
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, T);
             hipLaunchKernelGGL(k_chain_term_write, dim3((unsigned)div_up(T, CH_THREADS)), dim3(CH_THREADS), 0,
-                               ctx->stream, ctx->pk, tb.pos[res], T, td, sw.dir, sw.SA, ctx->CTX);
+                               ctx->stream, ctx->pk, tb.key[res], tb.pos[res], T, td, sw.dir, sw.SA, ctx->CTX);
             KCHECK(hipGetLastError());
         }
         for (int x = 0; x < 4; x++) sw.pos[x] += (int64_t)sw.dir * (int64_t)cnt[x];
@@ -697,7 +710,7 @@ __global__ void k_verify_part(const uint64_t *__restrict__ pk, const uint32_t *S
 {
     int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
-    uint32_t v = SA[i], cw = CTX[i];
+    uint32_t v = SA[i], cw = KISS_CTX_WORD(CTX[i]);
     bool ok = v < n && kiss_base(pk, v) == c;
     if (ok && cw != KISS_EMPTY_CTX) {
         uint32_t full = kiss_load_ctx(pk, v);
@@ -737,6 +750,7 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
 {
     ctx->stats.induce_passes = 0;
     KTRY(kiss_need_ctx_words(ctx));
+    ctx->ctx_words_valid = false;
     uint64_t cnt[4], cntS[4], cntL[4], cntLMS[4], start[5], lms_start[5];
     start[0] = 1;
     lms_start[0] = 0;
@@ -815,5 +829,6 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
             KTRY(run_pass(S, d_SA, ctx->CTX, (int64_t)(start[c] + cntL[c]) - 1, cntL[c], mask_lt, -1, tot, &done));
         }
     }
+    ctx->ctx_words_valid = true; // the taint bits of the words parallel to SA serve kiss_exact_refine
     return KISS_HIP_OK;
 }

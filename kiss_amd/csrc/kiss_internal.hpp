@@ -8,6 +8,12 @@
 
 #define KISS_EMPTY_CTX 1u      // context word with no bases left (marker bit only)
 #define KISS_CTX_BASES 15u     // bases carried in a 32-bit context word
+// Bit 31 of a context word (15 bases + marker use bits 0..30): "taint".  Set by the LMS sort / placement on every LMS
+// suffix whose place in the k-ordered list might not be its place in the exact order (tied through the depth with
+// another one, or ranked by the near-end rule), inherited unchanged by everything induced from it.  The exact-order
+// finish (kiss_exact_refine) then looks for tie groups only among tainted neighbours of the suffix array.
+#define KISS_CTX_TAINT 0x80000000u
+#define KISS_CTX_WORD(c) ((c) & 0x7FFFFFFFu)
 #define KISS_STRIDE 125u       // KISS1_SPLIT_SORT_STRIDE_DNA, algo/sort/constant.hpp:29
 
 // ---- error plumbing -----------------------------------------------------------
@@ -79,6 +85,7 @@ struct kiss_hip_ctx {
     uint64_t scan_tmp_cap = 0;
     // induce
     uint32_t *CTX = nullptr;       // context words parallel to SA (n+1)
+    bool ctx_words_valid = false;  // CTX holds the words of the last kiss_induce on this ctx (taint bits for the exact finish)
     uint32_t *ind_counts = nullptr;// 4 x tiles + 1
     uint64_t ind_tiles_cap = 0;
     uint32_t *d_small = nullptr;   // small scratch (64 u32) for single-workgroup kernels
@@ -96,7 +103,7 @@ struct kiss_hip_ctx {
     void *fm_pool[11] = {};
     uint64_t fm_pool_cap[11] = {};
     // near-end
-    uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr; // place.hip: near_reserve
+    uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr, *near_tmp2 = nullptr; // place.hip: near_reserve
     uint64_t near_cap = 0;
 
     // host-pointer entry points: device-side copies of the caller's S / SA (allocated on first use, api.hip) and the

@@ -46,14 +46,18 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_keys(const uint64_t *__re
 
 // true if suffix pi sorts before suffix pj, both already equal on [0, off + 32); bases from off + 32 on are
 // compared up to depth (0 = unbounded), ties go to the smaller index (= smaller text position)
+// *tied (optional) is set when the walk reached the depth without a difference: the order then is the tie rule's, and
+// both suffixes are tainted for the exact-order finish (KISS_CTX_TAINT)
 __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint64_t n, uint64_t pi, uint64_t pj,
-                                          uint64_t off, uint64_t depth, bool i_before_j)
+                                          uint64_t off, uint64_t depth, bool i_before_j, bool *tied = nullptr)
 {
     uint64_t d = off + 32;
     for (;;) {
-        if (depth && d >= depth) return i_before_j;
+        if ((depth && d >= depth) || (pi + d >= n && pj + d >= n)) { // (both off the text: not for two LMS suffixes)
+            if (tied) *tied = true;
+            return i_before_j;
+        }
         uint64_t qi = pi + d, qj = pj + d;
-        if (qi >= n && qj >= n) return i_before_j; // both ran off the text (does not happen for two LMS suffixes)
         if (qi + 96 < n && qj + 96 < n && (!depth || depth - d >= 128)) {
             // 128 bases per step: the ten word loads are independent, so one round trip to memory covers four
             // 32-base compares (the walk through a long repeat is a chain of dependent loads otherwise)
@@ -103,11 +107,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_adjacent(const uint64_t *__r
     const uint32_t a = segstart[sg], b = segstart[sg + 1];
     const uint32_t len = b - a;
     if (len < 3 || len > small_seg) return;
-    uint8_t ok = 1;
+    uint8_t ok = 1; // 0: my successor is smaller, 1: in order, 2: in order by the tie rule (equal through the depth)
     if ((uint32_t)i + 1 < b) {
         const uint64_t ki = key[i], kn = key[i + 1];
         if (kn != ki) ok = kn > ki;
-        else ok = !deep_less(pk, n, pos[i + 1], pos[i], off, depth, false);
+        else {
+            bool tied = false;
+            ok = !deep_less(pk, n, pos[i + 1], pos[i], off, depth, false, &tied);
+            if (tied) ok = 2;
+        }
     }
     inorder[i] = ok;
 }
@@ -141,6 +149,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
     const bool second_in_wave = small && (b - a == 2) && ((uint32_t)i == a + 1) && lane_id() > 0;
     uint32_t r = 0;
     uint64_t pi = 0;
+    // taint (KISS_CTX_TAINT): this item is tied with another one through the full depth (a walk of deep_less, here or in
+    // k_seg_adjacent, ended without a difference): its place among its mates is the tie rule's
+    bool taint = false;
     if (small) {
         pi = pos[i];
         if (!second_in_wave) {
@@ -152,26 +163,32 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
             }
             if (sorted) {
                 r = (uint32_t)i - a;
+                taint = ((uint32_t)i > a && inorder[i - 1] == 2) || ((uint32_t)i + 1 < b && inorder[i] == 2);
             } else {
                 for (uint32_t j = a; j < b; j++) {
                     if (j == (uint32_t)i) continue;
                     uint64_t kj = key[j];
                     bool jless;
                     if (kj != ki) jless = kj < ki;
-                    else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i);
+                    else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i, &taint);
                     r += jless ? 1u : 0u;
                 }
             }
         }
     }
     const uint32_t r_prev = __shfl_up(r, 1, 64);
-    if (second_in_wave) r = 1u - r_prev;
+    const bool t_prev = __shfl_up((int)taint, 1, 64) != 0;
+    if (second_in_wave) {
+        r = 1u - r_prev;
+        taint = t_prev; // the pair's first member did the comparison
+    }
     if (small) {
         const uint32_t dst = slot[a + r];
         out[dst] = (uint32_t)pi;
         // the context word a finished item brought along from round 0 (key payload) spares the placement step a
-        // random text gather; items that stay tied past this round get theirs gathered there
-        if (tctx) octx[dst] = tctx[i];
+        // random text gather; items that stay tied past this round get theirs gathered there (and are tainted there)
+        if (tctx) octx[dst] = tctx[i] | (taint ? KISS_CTX_TAINT : 0u);
+        else if (taint) octx[dst] = KISS_CTX_TAINT; // no word yet (gathered at placement), but tainted
         big[i] = 0;
     } else if (valid) {
         big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
@@ -417,8 +434,12 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_heads(const uint64_t *__re
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= nbig) return;
     const uint64_t k = key[i];
+    const bool complete = ((k >> complete_bit) & 1ull) != 0;
+    const bool same_prev = i > 0 && seg[i] == seg[i - 1] && key[i - 1] == k;
     uint8_t h = 1;
-    if (i > 0 && !((k >> complete_bit) & 1ull) && seg[i] == seg[i - 1] && key[i - 1] == k) h = 0;
+    if (same_prev && !complete) h = 0;
+    // bit 1: a complete key shared with a neighbour = equal through the full depth: final here by the tie rule (taint)
+    if (complete && (same_prev || (i + 1 < nbig && seg[i + 1] == seg[i] && key[i + 1] == k))) h |= 2;
     heads[i] = h;
 }
 
@@ -437,15 +458,18 @@ constexpr int FC_KEY = 0, FC_KEY_SEG = 1, FC_HEADS = 2;
 
 template <int SRC>
 __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const uint32_t *__restrict__ seg, uint64_t i,
-                                         uint64_t count, int cmp_shift, int last_round, bool &surv, bool &shead)
+                                         uint64_t count, int cmp_shift, int last_round, bool &surv, bool &shead,
+                                         bool *tie = nullptr) // *tie: the item shares everything compared with a neighbour
 {
     surv = shead = false;
+    if (tie) *tie = false;
     if (i >= count) return;
     bool head, nhead;
     if constexpr (SRC == FC_HEADS) {
         const uint8_t *hb = reinterpret_cast<const uint8_t *>(key);
         head = (i == 0) || hb[i] != 0;
         nhead = (i + 1 == count) || hb[i + 1] != 0;
+        if (tie) *tie = (hb[i] & 2) != 0; // the producer of the head bytes says so (k_pivot_heads)
     } else {
         constexpr bool HAS_SEG = SRC == FC_KEY_SEG;
         uint64_t k = key[i] >> cmp_shift;
@@ -455,6 +479,9 @@ __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const
     }
     surv = !(head && nhead) && !last_round;
     shead = surv && head;
+    if constexpr (SRC != FC_HEADS) {
+        if (tie) *tie = !(head && nhead);
+    }
 }
 
 template <int SRC>
@@ -501,18 +528,21 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
                                                           uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ isa,
-                                                          uint32_t *__restrict__ octx)
+                                                          uint32_t *__restrict__ octx,
+                                                          uint32_t *__restrict__ tmark) // taint marks of retiring items
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * FC_TILE + (uint64_t)wave * (FC_ITEMS * 64) + lane_id();
     uint32_t rs[FC_ITEMS], rh[FC_ITEMS]; // rank among survivors / surviving heads inside the wave (inclusive for heads)
     uint32_t fl = 0;                      // bit 2j = survivor, bit 2j+1 = surviving head
+    uint32_t tl = 0;                      // bit j = retires while tied with a neighbour (last round / complete pivot key)
     uint32_t ns = 0, nh = 0;
 #pragma unroll
     for (int j = 0; j < FC_ITEMS; j++) {
-        bool sv, sh;
-        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh);
+        bool sv, sh, ti;
+        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh, &ti);
+        tl |= (ti && !sv ? 1u : 0u) << j;
         const uint64_t ms = __ballot(sv), mh = __ballot(sh);
         rs[j] = ns + (uint32_t)__popcll(ms & lanemask_lt());
         rh[j] = nh + (uint32_t)__popcll(mh & lanemask_lt()) + (sh ? 1u : 0u);
@@ -547,6 +577,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             if (octx) octx[sl] = 0; // tied so far: its context word is gathered at placement
         } else {
             if (out) out[sl] = p;
+            if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
             if (isa) isa[p] = sl;
             if constexpr (SRC != FC_HEADS) {
                 if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
@@ -866,7 +897,7 @@ template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
                uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr, uint32_t *nctx = nullptr,
-               bool *nctx_written = nullptr)
+               bool *nctx_written = nullptr, uint32_t *tmark = nullptr)
 {
     if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
@@ -884,7 +915,7 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     else // (without slots an item's slot is its index: out == pos means the list is in place already)
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
-                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx);
+                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -897,7 +928,7 @@ int fused_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, c
     constexpr int SRC = HAS_SEG ? FC_KEY_SEG : FC_KEY;
     KTRY((fc_count<SRC>(ctx, key, seg, count, cmp_shift, last_round, d_total)));
     KTRY((fc_compact<SRC, HAS_SLOT>(ctx, key, seg, pos, slot, count, cmp_shift, last_round, npos, nslot, nseg, nsegstart,
-                                    ctx->lms_sorted_far, nullptr)));
+                                    ctx->lms_sorted_far, nullptr, nullptr, nullptr, nullptr, ctx->lms_ctx_far)));
     return fc_read_total(ctx, d_total, tot);
 }
 
@@ -1142,7 +1173,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             KTRY((fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, nbig, 0, 0, d_total)));
             KTRY(fc_read_total(ctx, d_total, &tot));
             KTRY((fc_compact<FC_HEADS, true>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, pb.pos[pres], ctx->bslot,
-                                            nbig, 0, 0, Pc, Sc, Gc, SSc, ctx->lms_sorted_far, nullptr)));
+                                            nbig, 0, 0, Pc, Sc, Gc, SSc, ctx->lms_sorted_far, nullptr, nullptr, nullptr, nullptr,
+                                            ctx->lms_ctx_far)));
             ctx->stats.big_item_rounds += nbig;
             count = tot >> 32;
             nseg = tot & 0xFFFFFFFFull;
@@ -1244,42 +1276,70 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 // =============================================================================================================
 namespace {
 
+// cw (optional): the context words the induction left parallel to SA.  Only their taint bit is looked at: a suffix that
+// does not descend from an LMS suffix the bounded-depth sort may have misplaced is where it belongs and starts a group of
+// its own -- no text is read for it (at chm13 size 94 % of the 3.1 G entries; this kernel was 69 ms of random reads).
 __global__ __launch_bounds__(LS_THREADS) void k_group_heads(const uint64_t *__restrict__ pk, uint64_t n,
                                                            const uint32_t *__restrict__ SA, uint64_t count, uint32_t h0,
-                                                           uint8_t *__restrict__ heads)
+                                                           const uint32_t *__restrict__ cw, uint8_t *__restrict__ heads)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     const bool valid = i < count;
     const uint64_t p = valid ? SA[i] : 0;
-    const bool pfull = valid && p + h0 <= n;
+    const bool tainted = valid && i > 0 && (!cw || (cw[i] & KISS_CTX_TAINT) != 0); // SA[0] = n has no context word
+    const bool pfull = tainted && p + h0 <= n;
     const uint64_t kp = pfull ? kiss_key32(pk, p) : 0ull; // h0 >= 32
     // predecessor's first word: from the neighbouring lane, lane 0 loads it
     uint64_t q = __shfl_up(p, 1, 64);
     uint64_t kq = __shfl_up(kp, 1, 64);
     bool qfull = __shfl_up((int)pfull, 1, 64) != 0;
-    if (lane_id() == 0 && valid && i > 0) {
+    if (lane_id() == 0 && pfull && i > 1) {
         q = SA[i - 1];
-        qfull = q + h0 <= n;
+        qfull = q + h0 <= n && (!cw || (cw[i - 1] & KISS_CTX_TAINT) != 0);
         kq = qfull ? kiss_key32(pk, q) : 0ull;
+    } else if (lane_id() == 0) {
+        qfull = false;
     }
     if (!valid) return;
     uint8_t head = 1;
     if (i > 0 && pfull && qfull && kp == kq) {
         head = 0;
-        for (uint32_t d = 32; d < h0; d += 32) {
+        uint32_t d = 32;
+        // 128 bases per step while that much is left (five independent word loads per suffix and step: tainted
+        // neighbours mostly ARE tied, so the walk usually runs the whole h0 bases)
+        for (; d + 128 <= h0 && !head; d += 128) {
+            uint64_t a[4], b[4];
+            keys128(pk, p + d, a);
+            keys128(pk, q + d, b);
+            if (a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) head = 1;
+        }
+        if (d < h0 && !head && h0 >= 160) { // the rest as ONE step that ends at h0 (it overlaps what has been compared)
+            uint64_t a[4], b[4];
+            keys128(pk, p + h0 - 128, a);
+            keys128(pk, q + h0 - 128, b);
+            if (a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) head = 1;
+            d = h0;
+        }
+        for (; d < h0 && !head; d += 32) {
             uint64_t a = kiss_key32(pk, p + d), b = kiss_key32(pk, q + d);
             if (h0 - d < 32) {
                 const uint64_t mask = ~0ull << (64 - 2 * (h0 - d));
                 a &= mask;
                 b &= mask;
             }
-            if (a != b) {
-                head = 1;
-                break;
-            }
+            if (a != b) head = 1;
         }
     }
     heads[i] = head;
+}
+
+// debug: number of tainted context words
+__global__ __launch_bounds__(LS_THREADS) void k_count_taint(const uint32_t *__restrict__ cw, uint64_t count,
+                                                           unsigned long long *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    const uint64_t m = __ballot(i > 0 && i < count && (cw[i] & KISS_CTX_TAINT));
+    if (lane_id() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 
 __global__ __launch_bounds__(LS_THREADS) void k_isa_init(const uint32_t *__restrict__ SA, uint64_t count,
@@ -1371,8 +1431,18 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     do {
         if (!heads_in) {
             KTimer t(ctx, KISS_HIP_K_GROUP_HEADS, total);
+            if (dbg && ctx->ctx_words_valid) {
+                unsigned long long *dc = (unsigned long long *)(ctx->d_small + 44), hc = 0;
+                KTRY(kiss_zero_u32(ctx, dc, 2));
+                hipLaunchKernelGGL(k_count_taint, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->CTX, total, dc);
+                KCHECK(hipMemcpyAsync(&hc, dc, 8, hipMemcpyDeviceToHost, ctx->stream));
+                KCHECK(hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffix-array entries are tainted\n", hc, (unsigned long long)total);
+            }
+            // the context words are still in CTX (it becomes the inverse suffix array only after this kernel)
+            static const bool no_taint = getenv("KISS_HIP_NO_TAINT") != nullptr; // A-B hook: compare every neighbour pair
             hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
-                               total, h0, heads);
+                               total, h0, (no_taint || !ctx->ctx_words_valid) ? (const uint32_t *)nullptr : ctx->CTX, heads);
         }
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
@@ -1383,6 +1453,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffixes tied at depth %u in %llu groups\n",
                     (unsigned long long)count, (unsigned long long)total, h0, (unsigned long long)nseg);
         if (count == 0) break;
+        ctx->ctx_words_valid = false; // CTX becomes the inverse suffix array from here on
         // the inverse suffix array is only needed when something is tied
         if (getenv("KISS_HIP_ISA_DIRECT")) { // measurement hook: the plain random scatter
             KTimer t(ctx, KISS_HIP_K_ISA, total);

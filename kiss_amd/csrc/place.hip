@@ -184,7 +184,9 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
         uint32_t xs[4] = {x.x, x.y, x.z, x.w}, cs[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int e = 0; e < 4; e++)
-            if (cs[e] == 0) cs[e] = kiss_load_ctx(pk, xs[e]); // not unique after round 0: gather
+            // no word from the sort (the suffix stayed tied past the first refinement round): gather it; the taint bit
+            // (kiss_internal.hpp: KISS_CTX_TAINT), set where the suffix retired tied, stays
+            if (KISS_CTX_WORD(cs[e]) == 0) cs[e] = kiss_load_ctx(pk, xs[e]) | (cs[e] & KISS_CTX_TAINT);
         const uint32_t lo0 = near_shift(near_sidx, E, i0), lo3 = E ? near_shift(near_sidx, E, i0 + 3) : 0u;
         if (lo0 == lo3) {
             U4 wp, wc;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
             const uint32_t lo = near_shift(near_sidx, E, i);
             const uint32_t x = far_sorted[i];
             uint32_t c = far_ctx[i];
-            if (c == 0) c = kiss_load_ctx(pk, x);
+            if (KISS_CTX_WORD(c) == 0) c = kiss_load_ctx(pk, x) | (c & KISS_CTX_TAINT);
             lmsP[i + lo] = x;
             lmsC[i + lo] = c;
         }
@@ -224,7 +226,68 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__res
     if (e >= E) return;
     uint32_t x = near_pos[e];
     lmsP[near_fin[e]] = x;
-    lmsC[near_fin[e]] = kiss_load_ctx(pk, x);
+    lmsC[near_fin[e]] = kiss_load_ctx(pk, x) | KISS_CTX_TAINT; // ranked by the scalar tail of the comparator: tie rules apply
+}
+
+// ---- taint of the far suffixes that TIE with a near-end suffix ------------------------------------------------
+// cmp(far f, near e) (kiss1_core.hpp:120-134) walks at most k bases; if f and e agree on all of them (e has between k
+// and D bases left) the smaller position wins, which is f: every far suffix that ties with e sorts immediately before
+// it.  Such an f may be unique among the far suffixes, so nothing else taints it -- but its place relative to e is a
+// tie-rule place, not an exact-order one.  The common prefix with e can only grow along the sorted list towards e, so
+// the run of far suffixes sharing >= k bases with e is found by a galloping + binary search from e's insertion index.
+__device__ __forceinline__ bool shares_k(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k, uint64_t f, uint64_t e)
+{
+    if (f + k > n || e + k > n) return false; // fewer than k bases left: a comparison ends at the end of the text
+    return cmp_bases(pk, f, e, k) == 0;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k,
+                                                             const uint32_t *__restrict__ far_sorted,
+                                                             const uint32_t *__restrict__ near_pos,
+                                                             const uint32_t *__restrict__ near_idx, uint32_t E,
+                                                             uint32_t *__restrict__ run_start)
+{
+    const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t pe = near_pos[e];
+    const uint64_t hi = near_idx[e]; // far suffixes [0, hi) sort before e
+    uint64_t lo = hi;                // first far index known to share k bases with e (hi: none yet)
+    uint64_t step = 1;
+    uint64_t bad = hi; // exclusive upper bound of indexes known NOT to share
+    // gallop towards the front while the suffix at lo - step still shares k bases
+    while (lo > 0) {
+        const uint64_t j = lo >= step ? lo - step : 0;
+        if (shares_k(pk, n, k, far_sorted[j], pe)) {
+            lo = j;
+            step *= 2;
+            if (j == 0) break;
+        } else {
+            bad = j + 1; // indexes <= j do not share; the run starts in (j, lo]
+            // binary search in [bad, lo)
+            uint64_t a = bad, b = lo;
+            while (a < b) {
+                const uint64_t mid = (a + b) >> 1;
+                if (shares_k(pk, n, k, far_sorted[mid], pe)) b = mid;
+                else a = mid + 1;
+            }
+            lo = a;
+            break;
+        }
+    }
+    (void)bad;
+    run_start[e] = (uint32_t)lo; // far suffixes [lo, hi) tie with e
+}
+
+// far_ctx[j] |= taint for j in [run_start[e], near_idx[e]): NT_BLOCKS workgroups per near suffix, grid-stride over its run
+constexpr uint32_t NT_BLOCKS = 16;
+__global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__restrict__ run_start,
+                                                             const uint32_t *__restrict__ near_idx,
+                                                             uint32_t *__restrict__ far_ctx)
+{
+    const uint32_t e = blockIdx.x / NT_BLOCKS, sub = blockIdx.x % NT_BLOCKS;
+    const uint64_t lo = run_start[e], hi = near_idx[e];
+    for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS)
+        far_ctx[j] |= KISS_CTX_TAINT; // (a word of 0 = "gather me" becomes 0x80000000: still gathered, see k_merge_far)
 }
 
 } // namespace
@@ -241,7 +304,7 @@ static int near_reserve(kiss_hip_ctx *ctx, uint64_t E)
     if (E <= ctx->near_cap && ctx->near_tmp) return KISS_HIP_OK;
     uint64_t cap = ctx->near_cap ? ctx->near_cap : 65536;
     while (cap < E) cap *= 2;
-    uint32_t **ptrs[] = {&ctx->near_idx, &ctx->near_fin, &ctx->near_pos, &ctx->near_tmp};
+    uint32_t **ptrs[] = {&ctx->near_idx, &ctx->near_fin, &ctx->near_pos, &ctx->near_tmp, &ctx->near_tmp2};
     for (uint32_t **p : ptrs) {
         if (*p) {
             (void)hipFree(*p);
@@ -260,7 +323,7 @@ static int near_reserve(kiss_hip_ctx *ctx, uint64_t E)
         *p = reinterpret_cast<uint32_t *>(q);
     }
     ctx->near_cap = cap;
-    ctx->ws_bytes += 4 * cap * sizeof(uint32_t);
+    ctx->ws_bytes += 5 * cap * sizeof(uint32_t);
     return KISS_HIP_OK;
 }
 
@@ -294,6 +357,12 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                            ctx->lms_sorted_far, m_far, near_sorted, E, ctx->near_idx);
         hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
+        if (m_far && (uint64_t)k < n) {
+            hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                               ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
+            hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                               ctx->lms_ctx_far);
+        }
         if (m_far)
             hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0,
                                ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_idx, E,
@@ -306,6 +375,12 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                            ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);
         hipLaunchKernelGGL(k_near_order, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
                            ctx->pk, n, (uint64_t)k, near_pos, ctx->near_idx, E, ctx->near_fin);
+        if (m_far && (uint64_t)k < n) {
+            hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                               ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
+            hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                               ctx->lms_ctx_far);
+        }
         KCHECK(hipGetLastError());
         // sorted insertion indexes for the merge (E is tiny: sort on the host)
         std::vector<uint32_t> idx(E);

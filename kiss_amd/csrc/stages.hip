@@ -181,8 +181,8 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
         KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
         if (d_far_ctx)
             KCHECK(hipMemcpyAsync(ctx->lms_ctx_far, d_far_ctx, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        else
-            KTRY(kiss_zero_u32(ctx, ctx->lms_ctx_far, m_far)); // no context words came along: gather them all
+        else // no context words came along: gather them all; nothing is known about ties either, so all are tainted
+            KCHECK(hipMemsetD32Async((hipDeviceptr_t)ctx->lms_ctx_far, (int)KISS_CTX_TAINT, m_far, ctx->stream));
     }
     if (near_count) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
         KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));

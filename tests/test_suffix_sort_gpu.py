@@ -157,7 +157,9 @@ def test_prefix_doubling_exact(ctx, oracle, shape):
         S = np.concatenate([base, gen.iid(100, 9), base[:n // 2 - 100 - 37]])
     st = _exact_by_doubling(ctx, oracle, S)
     assert st["refine_depth"] == 256
-    if shape in ("period1", "period2", "period7", "period400", "period5000", "nested", "tail_repeat"):
+    # (period1, a text of one base, has no LMS suffix at all: the induction yields the exact order by itself, nothing is
+    #  tainted and the doubling phase finds nothing to do)
+    if shape in ("period2", "period7", "period400", "period5000", "nested", "tail_repeat"):
         assert st["doubling_rounds"] >= 1 and st["refine_items"] > 0
         assert st["doubling_rounds"] <= 14  # log2(n / 256) + slack, not n / 32
 
