@@ -1333,6 +1333,82 @@ __global__ __launch_bounds__(LS_THREADS) void k_group_heads(const uint64_t *__re
     heads[i] = head;
 }
 
+// ---- group heads in two steps (the form used when the context words with their taint bits are at hand) ---------------
+// Only 5 % of the suffix-array entries of a genome are tainted; walked inside the one-lane-per-entry kernel above they
+// leave 61 of 64 lanes of nearly every wave waiting for three dependent random reads (29 ms at chm13 size, all latency).
+// Step 1 streams SA and the context words once: heads[i] = 1 for every entry that can not be tied with its
+// predecessor, and the indexes of the candidates (both tainted, both with h0 bases left) are appended to a list, one
+// atomic per workgroup -- spread over GH_REGIONS counters, each with its own slice of the list: three million adds to ONE
+// address take 36 ms, which is more than the kernel they were meant to speed up.  Step 2 compares the candidates' h0
+// bases with every lane busy.
+constexpr int GH_THREADS = 1024;
+constexpr int GH_REGIONS = 256;
+__global__ __launch_bounds__(GH_THREADS) void k_heads_candidates(const uint32_t *__restrict__ SA, uint64_t count, uint64_t n,
+                                                                uint32_t h0, const uint32_t *__restrict__ cw,
+                                                                uint8_t *__restrict__ heads, uint32_t *__restrict__ list,
+                                                                uint64_t region_cap, uint32_t *__restrict__ ncand)
+{
+    __shared__ uint32_t wcount[GH_THREADS / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t region = blockIdx.x % GH_REGIONS;
+    const uint64_t i = (uint64_t)blockIdx.x * GH_THREADS + threadIdx.x;
+    bool cand = false;
+    if (i < count) {
+        if (i > 1 && (cw[i] & KISS_CTX_TAINT) && (cw[i - 1] & KISS_CTX_TAINT)) {
+            const uint64_t p = SA[i], q = SA[i - 1];
+            cand = p + h0 <= n && q + h0 <= n;
+        }
+        heads[i] = 1; // candidates that turn out tied are reset by k_heads_compare
+    }
+    const uint64_t m = __ballot(cand);
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 0) wcount[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < GH_THREADS / 64; w++) {
+            const uint32_t c = wcount[w];
+            wcount[w] = t;
+            t += c;
+        }
+        s_base = t ? atomicAdd(&ncand[region], t) : 0u;
+    }
+    __syncthreads();
+    if (cand) {
+        const uint64_t at = (uint64_t)s_base + wcount[wave] + (uint64_t)__popcll(m & lanemask_lt());
+        if (at < region_cap) list[(uint64_t)region * region_cap + at] = (uint32_t)i; // (an overflow shows in the counter)
+    }
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_heads_compare(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ SA,
+                                                             const uint32_t *__restrict__ list, uint64_t region_cap,
+                                                             const uint32_t *__restrict__ ncand, uint32_t h0,
+                                                             uint8_t *__restrict__ heads)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x; // blockIdx.y = region
+    if (j >= ncand[blockIdx.y]) return;
+    const uint32_t i = list[(uint64_t)blockIdx.y * region_cap + j];
+    const uint64_t p = SA[i], q = SA[i - 1];
+    bool differ = false;
+    uint32_t d = 0;
+    for (; d + 128 <= h0 && !differ; d += 128) {
+        uint64_t a[4], b[4];
+        keys128(pk, p + d, a);
+        keys128(pk, q + d, b);
+        differ = a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || a[3] != b[3];
+    }
+    for (; d < h0 && !differ; d += 32) {
+        uint64_t a = kiss_key32(pk, p + d), b = kiss_key32(pk, q + d);
+        if (h0 - d < 32) {
+            const uint64_t mask = ~0ull << (64 - 2 * (h0 - d));
+            a &= mask;
+            b &= mask;
+        }
+        differ = a != b;
+    }
+    if (!differ) heads[i] = 0;
+}
+
 // debug: number of tainted context words
 __global__ __launch_bounds__(LS_THREADS) void k_count_taint(const uint32_t *__restrict__ cw, uint64_t count,
                                                            unsigned long long *__restrict__ out)
@@ -1441,8 +1517,31 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             }
             // the context words are still in CTX (it becomes the inverse suffix array only after this kernel)
             static const bool no_taint = getenv("KISS_HIP_NO_TAINT") != nullptr; // A-B hook: compare every neighbour pair
-            hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
-                               total, h0, (no_taint || !ctx->ctx_words_valid) ? (const uint32_t *)nullptr : ctx->CTX, heads);
+            bool done = false;
+            if (!no_taint && ctx->ctx_words_valid) {
+                // candidates first, compared densely afterwards; the list lives in posA (dead here).  More candidates than
+                // it holds (texts that are one repeat): the one-kernel form below does the whole job instead.
+                uint32_t *d_nc = ctx->rx_ghist; // GH_REGIONS counters (digit-histogram scratch of the radix sort, 3072 words, dead here)
+                const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
+                KTRY(kiss_zero_u32(ctx, d_nc, GH_REGIONS));
+                hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(total, GH_THREADS)), dim3(GH_THREADS), 0,
+                                   ctx->stream, d_SA, total, n, h0, ctx->CTX, heads, ctx->posA, region_cap, d_nc);
+                uint32_t h_nc[GH_REGIONS];
+                KCHECK(hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream));
+                KCHECK(hipStreamSynchronize(ctx->stream));
+                uint32_t mx = 0;
+                for (uint32_t v : h_nc) mx = v > mx ? v : mx;
+                if (mx <= region_cap) {
+                    if (mx)
+                        hipLaunchKernelGGL(k_heads_compare, dim3((unsigned)div_up((uint64_t)mx, T), GH_REGIONS), dim3(T), 0,
+                                           ctx->stream, ctx->pk, d_SA, ctx->posA, region_cap, d_nc, h0, heads);
+                    done = true;
+                }
+            }
+            if (!done)
+                hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
+                                   total, h0, (no_taint || !ctx->ctx_words_valid) ? (const uint32_t *)nullptr : ctx->CTX,
+                                   heads);
         }
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
