@@ -53,11 +53,11 @@ ALGO_BYTES = {
 }
 
 
-# HBM traffic measured with rocprofv3 PMC passes (tools/pmc.sh; profiles/r01_pmc_fetch_n5e8.csv and
-# profiles/r01_pmc_write_tcc_n5e8.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide streaming reads)
-# per algorithmic byte of the same launches (n = 5e8, 41 dispatches of k_radix_scatter<0,false,true>: the five round-0
-# passes of 145.4e6 items plus the small chain-collapse sorts): (2 x 4.604e6 KB + 9.277e6 KB) / (5 x 145.4e6 x 24 B
-# + <= 0.3e9 B) = 1.04 .. 1.06
+# HBM traffic measured with rocprofv3 PMC passes (tools/pmc.sh; profiles/r02_pmc_fetch_n5e8.csv and
+# profiles/r02_pmc_write_tcc_n5e8.csv, round 1: r01_pmc_*; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+# streaming reads) per algorithmic byte of the same launches (n = 5e8, 41 dispatches of k_radix_scatter<0,false,true>: the
+# five round-0 passes of 145.4e6 items plus the small chain-collapse sorts): (2 x 4.609e6 KB + 9.271e6 KB) /
+# (5 x 145.4e6 x 24 B + <= 0.3e9 B) = 1.04 .. 1.06 in both rounds (the kernel is unchanged)
 MEASURED_TRAFFIC_PER_ALGO_BYTE = {"radix_scatter": 1.05}
 
 
@@ -597,7 +597,7 @@ def main():
                         "traffic": (bytes_per_launch * MEASURED_TRAFFIC_PER_ALGO_BYTE[name]
                                     if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
                         "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
-                                        "kernel (separate rocprofv3 --pmc runs, profiles/r01_pmc_*.csv)",
+                                        "kernel (separate rocprofv3 --pmc runs, profiles/r02_pmc_*.csv)",
                         "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / args.steps,
                         "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
                         "kernel_ms_per_step": {kn: kv["ms"] / args.steps for kn, kv in agg.items() if kv["launches"]}}
