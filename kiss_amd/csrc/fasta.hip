@@ -394,9 +394,17 @@ int kiss_hip_ctx_load_text_file(kiss_hip_ctx *ctx, const char *path, uint8_t **d
             }
             if (hipStreamSynchronize(r.stream) != hipSuccess) status = KISS_HIP_E_HIP;
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < readers; t++) th.emplace_back(work, t);
+        std::vector<std::thread> th; // (no exception crosses the C ABI: a reader that can not start is run by this thread)
+        std::vector<int> orphan;
+        for (int t = 1; t < readers; t++) {
+            try {
+                th.emplace_back(work, t);
+            } catch (...) {
+                orphan.push_back(t);
+            }
+        }
         work(0);
+        for (int t : orphan) work(t);
         for (auto &x : th) x.join();
         rc = status;
         if (rc) break;

@@ -34,11 +34,14 @@ bool host_is_pinned(const void *p)
 int xfer_pool(kiss_hip_ctx *ctx)
 {
     if (ctx->xf_ready) return KISS_HIP_OK;
-    for (int t = 0; t < XF_THREADS; t++) {
-        if (hipStreamCreateWithFlags(&ctx->xf_stream[t], hipStreamNonBlocking) != hipSuccess) return KISS_HIP_E_HIP;
+    for (int t = 0; t < XF_THREADS; t++) { // (a call that failed half-way is resumed, not repeated)
+        if (!ctx->xf_stream[t] && hipStreamCreateWithFlags(&ctx->xf_stream[t], hipStreamNonBlocking) != hipSuccess)
+            return KISS_HIP_E_HIP;
         for (int b = 0; b < 2; b++) {
-            if (hipHostMalloc(&ctx->xf_pin[t][b], XF_CHUNK, hipHostMallocDefault) != hipSuccess) return KISS_HIP_E_NOMEM;
-            if (hipEventCreateWithFlags(&ctx->xf_done[t][b], hipEventDisableTiming) != hipSuccess) return KISS_HIP_E_HIP;
+            if (!ctx->xf_pin[t][b] && hipHostMalloc(&ctx->xf_pin[t][b], XF_CHUNK, hipHostMallocDefault) != hipSuccess)
+                return KISS_HIP_E_NOMEM;
+            if (!ctx->xf_done[t][b] && hipEventCreateWithFlags(&ctx->xf_done[t][b], hipEventDisableTiming) != hipSuccess)
+                return KISS_HIP_E_HIP;
         }
     }
     ctx->xf_ready = true;
@@ -106,9 +109,19 @@ int xfer_staged(kiss_hip_ctx *ctx, void *d, void *h, uint64_t bytes, bool to_dev
         }
         if (hipStreamSynchronize(st) != hipSuccess) status = KISS_HIP_E_HIP;
     };
+    // no exception may cross the C ABI: a thread that can not be started (std::system_error) just leaves its chunks to
+    // the calling thread
     std::vector<std::thread> th;
-    for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+    std::vector<int> orphan;
+    for (int t = 1; t < threads; t++) {
+        try {
+            th.emplace_back(work, t);
+        } catch (...) {
+            orphan.push_back(t);
+        }
+    }
     if (threads > 0) work(0);
+    for (int t : orphan) work(t);
     for (auto &x : th) x.join();
     return status;
 }
