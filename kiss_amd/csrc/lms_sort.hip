@@ -78,6 +78,28 @@ __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint6
             d += 128;
             continue;
         }
+        if (depth >= 128 && pi + depth <= n && pj + depth <= n) {
+            // fewer than 128 bases to go: ONE more step over the last 128 bases of the depth instead of up to four
+            // dependent 32-base steps.  It overlaps bases already found equal, which changes nothing: the first
+            // differing word still holds the first differing base.
+            const uint64_t ri = pi + depth - 128, rj = pj + depth - 128;
+            const uint64_t *wi = pk + (ri >> 5), *wj = pk + (rj >> 5);
+            const uint32_t si = 2u * (uint32_t)(ri & 31u), sj = 2u * (uint32_t)(rj & 31u);
+            uint64_t a[5], b[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                a[t] = wi[t];
+                b[t] = wj[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));
+                const uint64_t kj = (b[t] << sj) | ((b[t + 1] >> 1) >> (63u - sj));
+                if (ki != kj) return ki < kj;
+            }
+            if (tied) *tied = true;
+            return i_before_j;
+        }
         uint64_t ki = qi < n ? kiss_key32(pk, qi) : 0ull;
         uint64_t kj = qj < n ? kiss_key32(pk, qj) : 0ull;
         if (depth && depth - d < 32) {
