@@ -141,7 +141,8 @@ int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int a
 
 /* Same, on an existing ctx with host buffers (upload + sort + download).  The device-side copies of S and SA belong
  * to the ctx (allocated on the first call, kept for the next ones).  Page-locked host buffers (hipHostMalloc /
- * hipHostRegister) travel at the PCIe rate in one copy each; pageable ones are moved by 8 threads through page-locked
+ * hipHostRegister) travel at the PCIe rate, and for a bounded k the download of SA starts while the induction sweeps are
+ * still running (finished stretches leave on a copy stream); pageable ones are moved by 8 threads through page-locked
  * bounce buffers of the ctx.  kiss_hip_get_stats reports the wall time of both legs (ms_h2d, ms_d2h). */
 int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, int algo,
                                      uint32_t *SA);

@@ -86,6 +86,8 @@ int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
     return KISS_HIP_OK;
 }
 
+bool kiss_host_is_pinned(const void *p); // xfer.hip
+
 namespace {
 
 template <typename T>
@@ -524,9 +526,25 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
     const auto t0 = clk::now();
     KTRY(kiss_xfer_h2d(ctx, ctx->io_S, S, n));
     const auto t1 = clk::now();
-    KTRY(sort_dev(ctx, ctx->io_S, n, k, algo, ctx->io_SA, nullptr));
+    // bounded order into a page-locked buffer: finished stretches of SA leave while the sweeps still run (xfer.hip)
+    static const bool no_early = getenv("KISS_HIP_NO_EARLY_OUT") != nullptr; // A-B hook
+    const bool early = !no_early && n >= (1u << 22) && (uint64_t)k < n && kiss_host_is_pinned(SA);
+    ctx->early_used = 0;
+    ctx->early_bytes = 0;
+    ctx->early_host_SA = early ? SA : nullptr;
+    int rc = sort_dev(ctx, ctx->io_S, n, k, algo, ctx->io_SA, nullptr);
+    ctx->early_host_SA = nullptr;
     const auto t2 = clk::now();
-    KTRY(kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t)));
+    if (ctx->early_stream && ctx->early_used) {
+        const hipError_t e = hipStreamSynchronize(ctx->early_stream);
+        if (rc == KISS_HIP_OK && e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_HIP;
+        }
+    }
+    if (rc) return rc;
+    if (ctx->early_bytes != (n + 1) * sizeof(uint32_t)) // not armed, or (cannot happen) a stretch was not announced
+        KTRY(kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t)));
     const auto t3 = clk::now();
     ctx->stats.ms_h2d = std::chrono::duration<float, std::milli>(t1 - t0).count();
     ctx->stats.ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();

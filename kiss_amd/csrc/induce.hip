@@ -795,6 +795,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
             a = done ? L.pos[c] : a + (int64_t)N;
         }
         if ((uint64_t)L.pos[c] != start[c] + cntL[c]) return KINTERNAL();
+        // the L-type part of bucket c is final (later sources start with a larger base); slot 0 goes along with bucket A
+        KTRY(kiss_early_out(ctx, d_SA, c == 0 ? 0 : start[c], start[c] + cntL[c]));
         if (cntLMS[c]) {
             const uint32_t mask_gt = (0xFu << (c + 1)) & 0xFu; // S[v-1] > c for every LMS suffix
             KTRY(run_pass(L, ctx->lmsP, ctx->lmsC, (int64_t)lms_start[c], cntLMS[c], mask_gt, -1, tot, &done));
@@ -824,6 +826,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
                     (unsigned long long)(start[c] + cntL[c]));
             return KINTERNAL();
         }
+        // the S-type part of bucket c is final: what is appended from here on starts with a smaller base
+        KTRY(kiss_early_out(ctx, d_SA, start[c] + cntL[c], start[c + 1]));
         if (cntL[c] && c > 0) {
             const uint32_t mask_lt = (1u << c) - 1u; // L-type source of char c: v-1 is S-type iff S[v-1] < c
             KTRY(run_pass(S, d_SA, ctx->CTX, (int64_t)(start[c] + cntL[c]) - 1, cntL[c], mask_lt, -1, tot, &done));

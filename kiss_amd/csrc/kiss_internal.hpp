@@ -111,6 +111,13 @@ struct kiss_hip_ctx {
     uint8_t *io_S = nullptr;
     uint32_t *io_SA = nullptr;
     uint64_t io_cap = 0; // bases
+    // early download (api.hip / induce.hip): while the sweeps still run, finished stretches of SA leave for a page-locked
+    // host buffer on a copy stream of their own
+    uint32_t *early_host_SA = nullptr; // non-null only inside a host-pointer call whose SA buffer is page-locked
+    hipStream_t early_stream = nullptr;
+    std::vector<hipEvent_t> early_events;
+    size_t early_used = 0;
+    uint64_t early_bytes = 0;
     void *xf_pin[8][2] = {};
     hipEvent_t xf_done[8][2] = {};
     hipStream_t xf_stream[8] = {};
@@ -184,6 +191,8 @@ int kiss_xfer_d2h(kiss_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t by
 void kiss_xfer_free(kiss_hip_ctx *ctx);
 // induced sort sweeps -> d_SA
 int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA);
+// SA[lo, hi) is final: if an early download is armed (ctx->early_host_SA), send it off on the copy stream now
+int kiss_early_out(kiss_hip_ctx *ctx, const uint32_t *d_SA, uint64_t lo, uint64_t hi);
 
 // ---- device helpers ----------------------------------------------------------------
 #ifdef __HIPCC__

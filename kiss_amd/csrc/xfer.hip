@@ -128,8 +128,38 @@ int xfer_staged(kiss_hip_ctx *ctx, void *d, void *h, uint64_t bytes, bool to_dev
 
 } // namespace
 
+// ---- early download --------------------------------------------------------------------------------------------
+// The reference's timed region ends with SA in host memory; 12.5 GB at 57 GB/s is 218 ms, more than twice the sort.  The
+// L-type part of a bucket is final once the L sweep has passed it, the S-type part once the S sweep has: each such
+// stretch is queued on a copy stream behind an event of the compute stream, so the PCIe transfer starts while the sweeps
+// are still running instead of after them.  Armed only for page-locked destinations and the bounded orders (the
+// exact-order finish rewrites SA afterwards).
+int kiss_early_out(kiss_hip_ctx *ctx, const uint32_t *d_SA, uint64_t lo, uint64_t hi)
+{
+    if (!ctx->early_host_SA || hi <= lo) return KISS_HIP_OK;
+    if (!ctx->early_stream) KCHECK(hipStreamCreateWithFlags(&ctx->early_stream, hipStreamNonBlocking));
+    if (ctx->early_used == ctx->early_events.size()) {
+        hipEvent_t e;
+        KCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->early_events.push_back(e);
+    }
+    hipEvent_t ev = ctx->early_events[ctx->early_used++];
+    KCHECK(hipEventRecord(ev, ctx->stream));
+    KCHECK(hipStreamWaitEvent(ctx->early_stream, ev, 0));
+    KCHECK(hipMemcpyAsync(ctx->early_host_SA + lo, d_SA + lo, (hi - lo) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          ctx->early_stream));
+    ctx->early_bytes += (hi - lo) * sizeof(uint32_t);
+    return KISS_HIP_OK;
+}
+
+bool kiss_host_is_pinned(const void *p) { return host_is_pinned(p); }
+
 void kiss_xfer_free(kiss_hip_ctx *ctx)
 {
+    for (hipEvent_t e : ctx->early_events) (void)hipEventDestroy(e);
+    ctx->early_events.clear();
+    if (ctx->early_stream) (void)hipStreamDestroy(ctx->early_stream);
+    ctx->early_stream = nullptr;
     for (int t = 0; t < XF_THREADS; t++) {
         for (int b = 0; b < 2; b++) {
             if (ctx->xf_pin[t][b]) (void)hipHostFree(ctx->xf_pin[t][b]);

@@ -405,3 +405,28 @@ def test_pivot_rounds_equal_32_base_rounds(oracle, monkeypatch, k):
             assert np.array_equal(a, want), "pivot rounds"
             assert np.array_equal(b, want), "32-base rounds"
             assert np.array_equal(d, want), "pivot rounds from the second round on, one deviation per key"
+
+
+@pytest.mark.parametrize("k", [32, 256])
+def test_host_entry_with_page_locked_buffers_downloads_early(oracle, monkeypatch, k):
+    # kiss_hip_ctx_suffix_sort_dna_u32 with page-locked host buffers: the finished stretches of SA (L-type part of a bucket
+    # after the L sweep has passed it, S-type part after the S sweep has) are downloaded while the sweeps still run;
+    # KISS_HIP_NO_EARLY_OUT (read once per process) is covered by the pageable call, which never arms it
+    import torch
+    import kiss_amd
+    S = gen.genome_like(6_000_000, 23)
+    want = oracle.suffix_sort(S, k)
+    S_pin = torch.from_numpy(S).pin_memory()
+    SA_pin = torch.empty(S.size + 1, dtype=torch.int32).pin_memory()
+    with kiss_amd.Context(max_n=S.size, device=0) as c:
+        for _ in range(2):  # the second call reuses the ctx-owned device copies, the copy stream and its events
+            SA_pin.fill_(-1)
+            c.suffix_sort_host(S_pin.numpy(), SA_pin.numpy().view(np.uint32), k=k)
+            assert np.array_equal(SA_pin.numpy().view(np.uint32), want)
+        SA_page = np.full(S.size + 1, 0xFFFFFFFF, dtype=np.uint32)
+        c.suffix_sort_host(S, SA_page, k=k)
+        assert np.array_equal(SA_page, want)
+        # exact order is never downloaded early (the doubling phase rewrites SA after the sweeps)
+        SA_pin.fill_(-1)
+        c.suffix_sort_host(S_pin.numpy(), SA_pin.numpy().view(np.uint32), k=0xFFFFFFFF, algo=kiss_amd.ALGO_PREFIX_DOUBLING)
+        assert np.array_equal(SA_pin.numpy().view(np.uint32), oracle.suffix_sort(S, 0xFFFFFFFF))
