@@ -95,8 +95,11 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
 {
     void *q = nullptr;
     uint64_t bytes = (count ? count : 1) * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes);
+    // fault-injection hook of tests/test_suffix_sort_gpu.py: work arrays above this many bytes "do not fit"
+    const char *cap = getenv("KISS_HIP_FAIL_ALLOC_OVER");
+    hipError_t e = cap && bytes > strtoull(cap, nullptr, 10) ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
     if (e != hipSuccess) {
+        (void)hipGetLastError(); // (or the next launch check reports this failure as its own)
         ctx->last_hip_error = (int)e;
         return KISS_HIP_E_NOMEM;
     }
@@ -166,6 +169,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
     if (algo != KISS_HIP_ALGO_PARALLEL_SORTING && algo != KISS_HIP_ALGO_PREFIX_DOUBLING) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     std::memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n = n;
     ctx->stats.k = k;
@@ -264,6 +268,23 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
 
 } // namespace
 
+// LMS-sized arrays: DNA has ~0.29-0.30 n LMS suffixes; inputs with more (up to n/2) re-reserve on demand
+static uint64_t default_m_cap(const kiss_hip_ctx *ctx)
+{
+    uint64_t m0 = (uint64_t)(0.32 * (double)ctx->max_n) + 4096;
+    if (m0 > ctx->max_n / 2 + 2) m0 = ctx->max_n / 2 + 2;
+    return m0;
+}
+
+// A call that ran out of memory while growing its work arrays leaves them released (never half-allocated); the next call
+// starts from the default reservation again instead of failing on what the previous one left behind.
+int kiss_workspace_ready(kiss_hip_ctx *ctx)
+{
+    (void)hipGetLastError(); // a failed allocation of an earlier call is not this call's error
+    if (ctx->m_cap && ctx->t_cap && ctx->lms_pos && ctx->flags) return KISS_HIP_OK;
+    return kiss_lms_reserve(ctx, default_m_cap(ctx));
+}
+
 // CTX (4 bytes per base: context words of the sweeps, later the inverse SA of the doubling phase) is only needed by the
 // process that runs the induction: allocated on first use, so that ranks > 0 of a sharded sort never hold it
 int kiss_need_ctx_words(kiss_hip_ctx *ctx)
@@ -306,7 +327,11 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         if (hipMemset(ctx->rx_desc, 0, 256 * ctx->rx_tiles_cap * sizeof(uint64_t)) != hipSuccess) rc = KISS_HIP_E_HIP;
     } while (0);
     ctx->lms_bytes = ctx->ws_bytes - before;
-    if (rc) return rc;
+    if (rc) { // leave nothing half-allocated behind: the next call starts from the default reservation again
+        free_lms_side(ctx);
+        ctx->m_cap = 0;
+        return rc;
+    }
     // tied-segment arrays: on genome-like text 18 % of the LMS suffixes survive round 0; they grow on demand
     // (all-tied inputs such as periodic texts end up at m_cap)
     uint64_t t0 = m_cap / 4 + (4ull << 20);
@@ -352,6 +377,8 @@ int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
     if (rc == KISS_HIP_OK) {
         ctx->t_cap = t_cap;
         ctx->flags_cap = fcap;
+    } else {
+        free_tied(ctx); // (t_cap = 0: kiss_workspace_ready re-reserves the default before the next sort)
     }
     return rc;
 }
@@ -423,10 +450,7 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
 
         ALLOC(d_small, 64);
 #undef ALLOC
-        // LMS-sized arrays: DNA has ~0.29-0.30 n LMS suffixes; inputs with more (up to n/2) re-reserve on demand
-        uint64_t m0 = (uint64_t)(0.32 * (double)max_n) + 4096;
-        if (m0 > max_n / 2 + 2) m0 = max_n / 2 + 2;
-        if ((rc = kiss_lms_reserve(ctx, m0))) break;
+        if ((rc = kiss_lms_reserve(ctx, default_m_cap(ctx)))) break;
         void *hp = nullptr;
         if (hipHostMalloc(&hp, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
             rc = KISS_HIP_E_NOMEM;

@@ -262,6 +262,7 @@ int kiss_hip_ctx_parse_text_dev(kiss_hip_ctx *ctx, const uint8_t *d_raw, uint64_
     if (bytes > 0xFFFFFFF0ull) return KISS_HIP_E_INVALID; // line numbers and offsets are 32-bit (n < 2^32 anyway)
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     *n_out = 0;
     if (bytes == 0) return KISS_HIP_OK;
     const uint64_t tiles = div_up(bytes, FA_TILE);

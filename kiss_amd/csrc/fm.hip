@@ -482,6 +482,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     if (fmi->sa_intv != 4) return KISS_HIP_E_UNSUPPORTED; // the CLI's FMIndex<4, ...> (fmindex_build.hpp:27)
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     if (hit_count_total) *hit_count_total = 0;
     if (checksum) *checksum = 0;
     if (Q == 0) return KISS_HIP_OK;
@@ -571,6 +572,7 @@ int kiss_hip_fmi_build_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, co
     if (n > KISS_HIP_MAX_N) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     const uint64_t N = n + 1;
     const uint64_t chunks = N / 16 + 1, blocks = N / 256 + 1;
     const uint64_t words = (N + 63) / 64, nbocc = N / 64 + 1;

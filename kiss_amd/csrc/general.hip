@@ -59,6 +59,7 @@ int kiss_hip_ctx_suffix_sort_u8_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint6
     if (n > KISS_HIP_MAX_N || n > ctx->max_n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     std::memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n = n;
     ctx->stats.k = 0xFFFFFFFFu;

@@ -150,6 +150,8 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
 // (re)allocates the tied-segment arrays (seg*, slot*, segstart*, bkey*, bpos*, bseg*, bslot, flags) for t_cap items;
 // their contents are lost
 int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap);
+// re-reserves the default work arrays if an earlier call released them on running out of memory
+int kiss_workspace_ready(kiss_hip_ctx *ctx);
 // allocates ctx->CTX (max_n + 2 words) on first use: only the process that runs the induction / doubling phase holds it
 int kiss_need_ctx_words(kiss_hip_ctx *ctx);
 int kiss_pack_text(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n);

@@ -56,6 +56,7 @@ int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, u
     if (!ctx || !d_S || !counts13 || n == 0 || n > ctx->max_n || lo > hi || hi > n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     std::memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n = n;
     ctx->stats.k = k;
@@ -89,6 +90,7 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
     if (!ctx || !d_hist || bits < 1 || bits > 24 || (count && !d_keys)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     KTRY(kiss_zero_u32(ctx, d_hist, 2ull << bits));
     if (count) {
         hipLaunchKernelGGL(k_key_hist, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
@@ -108,6 +110,7 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
     if (count > ctx->m_cap) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     if (count == 0) return KISS_HIP_OK;
     if (count > ctx->t_cap) KTRY(kiss_tied_reserve(ctx, count + count / 64 + 1024)); // group ids use the segment arrays
     Splitters sp;
@@ -142,6 +145,7 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     if (count && (!d_keys || !d_pos || !d_sorted_out)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     if (count > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, count + count / 64 + 1024));
     if (count) {
         KCHECK(hipMemcpyAsync(ctx->keyA, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -175,6 +179,7 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     const uint64_t m = m_far + near_count;
     if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
     if (m_far) {
@@ -206,6 +211,7 @@ int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint
     if (h0 < 32 || n < 4ull * h0 + 1024) return KISS_HIP_E_UNSUPPORTED;
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    KTRY(kiss_workspace_ready(ctx));
     KTRY(kiss_exact_refine(ctx, n, h0, d_SA));
     KCHECK(hipStreamSynchronize(ctx->stream));
     KTRY(kiss_radix_check(ctx));

@@ -238,6 +238,34 @@ def test_error_codes(ctx):
     assert sa[0] == S.size and sorted(sa.tolist()) == list(range(S.size + 1))
 
 
+def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
+    # a text with more LMS suffixes than the DNA-typical reservation makes the work arrays grow; when that growth does not
+    # fit (fault injection: arrays over 700 kB "do not fit") the call reports KISS_HIP_E_NOMEM, and the same context sorts the
+    # next text as if nothing had happened (found by tools/stress_verify.py at n = 2.4e9: it did not)
+    import kiss_amd
+    from kiss_amd import _lib
+    n = 200_000   # default reservation: 0.32 n LMS suffixes (545 kB of keys); ACAC.. has n/2 (821 kB)
+    c = kiss_amd.Context(max_n=n, device=0)
+    try:
+        dna = gen.iid(n, 77)
+        acac = np.tile(np.array([0, 1], np.uint8), n // 2)              # n/2 LMS suffixes, all of them tied
+        want_dna = oracle.suffix_sort(dna, 256)
+        assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
+        for k in (256, 0xFFFFFFFF):
+            monkeypatch.setenv("KISS_HIP_FAIL_ALLOC_OVER", "700000")
+            with pytest.raises(kiss_amd.KissHipError) as e:
+                c.suffix_sort(acac, k)
+            assert e.value.status == _lib.KISS_HIP_E_NOMEM
+            with pytest.raises(kiss_amd.KissHipError) as e:             # still failing while memory is short, still cleanly
+                c.suffix_sort(acac, k)
+            assert e.value.status == _lib.KISS_HIP_E_NOMEM
+            monkeypatch.delenv("KISS_HIP_FAIL_ALLOC_OVER")
+            assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
+            assert np.array_equal(c.suffix_sort(acac, k), oracle.suffix_sort(acac, k))
+    finally:
+        c.close()
+
+
 def _random_text(rng, n):
     """small adversarial texts: mixtures of i.i.d. stretches, runs, tandem repeats and copies of earlier pieces"""
     out = []
