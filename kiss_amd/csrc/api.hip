@@ -631,6 +631,11 @@ int kiss_hip_ctx_get_stage_outputs(kiss_hip_ctx *ctx, uint32_t *lms_ascending, u
     KCHECK(hipSetDevice(ctx->device));
     if (lms_ascending && ctx->m)
         KCHECK(hipMemcpy(lms_ascending, ctx->lms_pos, ctx->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (lms_sorted && ctx->m) {
+        ctx->stream = ctx->own_stream;
+        KTRY(kiss_merge_lms(ctx)); // the sort itself never builds the merged list (place.hip)
+        KCHECK(hipStreamSynchronize(ctx->stream));
+    }
     if (lms_sorted && ctx->m)
         KCHECK(hipMemcpy(lms_sorted, ctx->lmsP, ctx->m * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (counts)

@@ -38,14 +38,52 @@ __device__ __forceinline__ uint32_t child_ctx(uint32_t parent)
     return (KISS_CTX_WORD(parent) >> 2) | (parent & KISS_CTX_TAINT);
 }
 
-// class of a source item: 0..3 = append v-1 to bucket of that base, 4 = nothing to append
-__device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
-                                               int64_t phys, uint32_t emitmask, uint32_t *v_out, uint32_t *ctx_out)
+// The sorted LMS list is read where the LMS sort left it (ctx->lms_sorted_far / lms_ctx_far) instead of from a merged copy
+// (place.hip): the handful of near-end suffixes, ranked by the scalar tail of the comparator, live in a small table
+// sorted by their index in the merged list.  Merged index j holds near-end suffix t if fin[t] == j, else far suffix
+// j - #{t : fin[t] < j}.
+struct LmsRemap {
+    const uint32_t *fin;  // merged index of the t-th near-end suffix, ascending
+    const uint32_t *npos; // its text position
+    uint32_t E;
+};
+
+__device__ __forceinline__ uint32_t remap_below(const LmsRemap &rm, uint64_t j) // #{t : fin[t] < j}
 {
+    uint32_t lo = 0, hi = rm.E;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)rm.fin[mid] < j) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// class of a source item: 0..3 = append v-1 to bucket of that base, 4 = nothing to append.
+// A word without bases (KISS_EMPTY_CTX: run empty; 0: a far LMS suffix that left the sort without one) is gathered
+// from the text and kept.  REMAP: idx is an index into the merged LMS list (see LmsRemap), else a physical one.
+template <bool REMAP>
+__device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
+                                               int64_t idx, uint32_t emitmask, uint32_t *v_out, uint32_t *ctx_out,
+                                               const LmsRemap &rm)
+{
+    int64_t phys = idx;
+    if (REMAP) {
+        const uint32_t t = remap_below(rm, (uint64_t)idx);
+        if (t < rm.E && (int64_t)rm.fin[t] == idx) { // a near-end suffix: placed by the tie rules, so tainted
+            const uint32_t v = rm.npos[t];
+            const uint32_t c = kiss_load_ctx(pk, v) | KISS_CTX_TAINT;
+            *v_out = v;
+            *ctx_out = c;
+            const uint32_t pc = c & 3u;
+            return (v != 0 && ((emitmask >> pc) & 1u)) ? pc : 4u;
+        }
+        phys = idx - (int64_t)t;
+    }
     uint32_t c = srcC[phys];
     uint32_t v = srcP[phys];
     *v_out = v;
-    if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) {
+    if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) {
         if (v == 0) {
             *ctx_out = c;
             return 4u;
@@ -58,16 +96,21 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
     return ((emitmask >> pc) & 1u) ? pc : 4u;
 }
 
-// the count pass only needs the class: the position is read only when the context word has run empty
+// the count pass only needs the class: the position is read only when the context word has no bases
+template <bool REMAP>
 __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
-                                                    int64_t phys, uint32_t emitmask)
+                                                    int64_t idx, uint32_t emitmask, const LmsRemap &rm)
 {
-    uint32_t c = srcC[phys];
-    if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) {
-        const uint32_t v = srcP[phys];
+    if (REMAP) {
+        uint32_t v, c;
+        return item_class<true>(pk, srcP, srcC, idx, emitmask, &v, &c, rm);
+    }
+    uint32_t c = srcC[idx];
+    if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) {
+        const uint32_t v = srcP[idx];
         if (v == 0) return 4u;
         c = kiss_load_ctx(pk, v) | (c & KISS_CTX_TAINT);
-        srcC[phys] = c;
+        srcC[idx] = c;
     }
     const uint32_t pc = c & 3u;
     return ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -77,10 +120,11 @@ __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__
 // One WAVE per tile (a workgroup = IN_WAVES tiles): counting does not care about order, so a lane takes four
 // consecutive items per step (16-byte loads, all of the tile's steps in flight at once) and keeps the four class
 // counts in 16-bit fields of one 64-bit word (a tile has 2048 items); no LDS, no barrier, no atomic.
+template <bool REMAP>
 __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                             uint32_t *srcC, int64_t beg, uint64_t N, int dir,
                                                             uint32_t emitmask, uint32_t *__restrict__ counts,
-                                                            uint64_t tiles)
+                                                            uint64_t tiles, LmsRemap rm)
 {
     if (blockIdx.x == 0 && threadIdx.x == 4) counts[4 * tiles] = 0; // the extra last entry of the scan input
     const uint64_t tile = (uint64_t)blockIdx.x * IN_WAVES + (threadIdx.x >> 6);
@@ -92,13 +136,22 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     const uint32_t lane = lane_id();
     const uint64_t t0 = tile * IN_TILE;
     uint64_t acc = 0;
-    if (t0 + IN_TILE <= N) {
+    // REMAP (dir > 0 only): the tile is read as a block when no near-end suffix falls inside it -- then its items are
+    // consecutive entries of the far list, `shift` entries below their merged index
+    int64_t shift = 0;
+    bool block = t0 + IN_TILE <= N;
+    if (REMAP && block) {
+        const uint32_t b0 = remap_below(rm, (uint64_t)beg + t0);
+        block = b0 == remap_below(rm, (uint64_t)beg + t0 + IN_TILE);
+        shift = (int64_t)b0;
+    }
+    if (block) {
         U4 t[STEPS];
         int64_t p0[STEPS];
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
             const uint64_t i0 = t0 + (uint64_t)q * 256 + 4 * lane;
-            p0[q] = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + 3); // lowest address of my four items
+            p0[q] = (dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + 3)) - shift; // lowest address of my four items
             t[q] = *reinterpret_cast<const U4 *>(srcC + p0[q]);
         }
 #pragma unroll
@@ -107,7 +160,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
             for (int e = 0; e < 4; e++) {
                 const uint32_t c = t[q].v[e];
                 uint32_t cls;
-                if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) cls = item_class_only(pk, srcP, srcC, p0[q] + e, emitmask); // refresh path
+                if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class_only<false>(pk, srcP, srcC, p0[q] + e, emitmask, rm); // refresh path
                 else {
                     const uint32_t pc = c & 3u;
                     cls = ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -117,7 +170,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
         }
     } else {
         for (uint64_t i = t0 + lane; i < N && i < t0 + IN_TILE; i += 64) {
-            const uint32_t cls = item_class_only(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask);
+            const uint32_t cls = item_class_only<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, rm);
             acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
         }
     }
@@ -131,11 +184,12 @@ struct DstPos {
 };
 
 // ---- pass 2: stable scatter ------------------------------------------------------------
+template <bool REMAP>
 __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                               uint32_t *srcC, int64_t beg, uint64_t N, int dir,
                                                               uint32_t emitmask, const uint32_t *__restrict__ ex,
                                                               uint64_t tiles, DstPos dst, uint32_t *SA, uint32_t *CTX,
-                                                              uint32_t *__restrict__ totals)
+                                                              uint32_t *__restrict__ totals, LmsRemap rm)
 {
     __shared__ uint32_t wtot[IN_WAVES][4];
     // items appended per class = differences of the scanned counts (4 * tiles + 1 entries)
@@ -150,8 +204,15 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
     const uint64_t i0 = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
     uint32_t vv[IN_ITEMS], cc[IN_ITEMS], rr[IN_ITEMS]; // rr = (class << 28) | rank in wave
     uint32_t cnt[4] = {0, 0, 0, 0};
-    if (i0 + IN_ITEMS <= N) {
-        const int64_t p0 = dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1); // lowest address of my items
+    int64_t shift = 0; // REMAP (dir > 0 only): see k_induce_count
+    bool block = i0 + IN_ITEMS <= N;
+    if (REMAP && block) {
+        const uint32_t b0 = remap_below(rm, (uint64_t)beg + i0);
+        block = b0 == remap_below(rm, (uint64_t)beg + i0 + IN_ITEMS);
+        shift = (int64_t)b0;
+    }
+    if (block) {
+        const int64_t p0 = (dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1)) - shift; // lowest address of my items
         uint32_t bp[IN_ITEMS], bc[IN_ITEMS];
 #pragma unroll
         for (int q = 0; q < IN_ITEMS / 4; q++) {
@@ -167,7 +228,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         for (int e = 0; e < IN_ITEMS; e++) {
             const int a = dir > 0 ? e : IN_ITEMS - 1 - e; // place of item e inside the block
             uint32_t v = bp[a], c = bc[a], cls;
-            if (KISS_CTX_WORD(c) == KISS_EMPTY_CTX) cls = item_class(pk, srcP, srcC, p0 + a, emitmask, &v, &c); // refresh path
+            if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm); // refresh path
             else {
                 const uint32_t pc = c & 3u;
                 cls = ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -187,7 +248,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         for (int e = 0; e < IN_ITEMS; e++) {
             const uint64_t i = i0 + (uint64_t)e;
             uint32_t cls = 4u, v = 0, c = 0;
-            if (i < N) cls = item_class(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &c);
+            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &c, rm);
             uint32_t local = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -286,10 +347,11 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
 // ---- single-workgroup chain kernel -----------------------------------------------------
 // Processes one source segment and, when selfclass >= 0, keeps processing what it appended to that
 // class until nothing is appended any more.  out[0..3] = items appended per class, out[4] = rounds.
+template <bool REMAP> // REMAP: one round over the LMS list (selfclass < 0)
 __global__ __launch_bounds__(SM_THREADS) void k_induce_small(const uint64_t *__restrict__ pk, const uint32_t *srcP0,
                                                             uint32_t *srcC0, int64_t beg0, uint64_t N0, int dir,
                                                             uint32_t emitmask, int selfclass, DstPos dst, uint32_t *SA,
-                                                            uint32_t *CTX, uint32_t *out)
+                                                            uint32_t *CTX, uint32_t *out, LmsRemap rm)
 {
     __shared__ int64_t heads[4];
     __shared__ uint32_t wtot[SM_THREADS / 64][4];
@@ -313,7 +375,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_induce_small(const uint64_t *__r
         for (uint64_t cb = 0; cb < N; cb += SM_THREADS) {
             uint64_t i = cb + threadIdx.x;
             uint32_t cls = 4u, v = 0, cw = 0;
-            if (i < N) cls = item_class(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &cw);
+            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &cw, rm);
             uint32_t myrank = 0;
             uint32_t tot[4];
 #pragma unroll
@@ -368,9 +430,11 @@ struct Sweep {
 
 // one source segment; returns items appended per class in tot[4]
 int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint64_t N, uint32_t emitmask,
-             int selfclass, uint64_t tot[4], bool *chain_done)
+             int selfclass, uint64_t tot[4], bool *chain_done, const LmsRemap *remap = nullptr)
 {
     kiss_hip_ctx *ctx = sw.ctx;
+    const LmsRemap rm = remap ? *remap : LmsRemap{nullptr, nullptr, 0u};
+    if (remap && (sw.dir < 0 || selfclass >= 0)) return KINTERNAL();
     for (int c = 0; c < 4; c++) tot[c] = 0;
     *chain_done = false;
     if (N == 0 || emitmask == 0) {
@@ -383,8 +447,12 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
     if (N <= SMALL_MAX) {
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
-            hipLaunchKernelGGL(k_induce_small, dim3(1), dim3(SM_THREADS), 0, ctx->stream, ctx->pk, srcP, srcC, beg, N,
-                               sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small);
+            if (remap)
+                hipLaunchKernelGGL(k_induce_small<true>, dim3(1), dim3(SM_THREADS), 0, ctx->stream, ctx->pk, srcP, srcC, beg, N,
+                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+            else
+                hipLaunchKernelGGL(k_induce_small<false>, dim3(1), dim3(SM_THREADS), 0, ctx->stream, ctx->pk, srcP, srcC, beg, N,
+                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_readback(ctx, ctx->d_small, 5));
@@ -395,15 +463,23 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         if (4 * tiles + 1 > ctx->ind_tiles_cap) return KINTERNAL();
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
-            hipLaunchKernelGGL(k_induce_count, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                               srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles);
+            if (remap)
+                hipLaunchKernelGGL(k_induce_count<true>, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream,
+                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm);
+            else
+                hipLaunchKernelGGL(k_induce_count<false>, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream,
+                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_scan_u32(ctx, ctx->ind_counts, ctx->ind_counts, 4 * tiles + 1));
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SCATTER, N);
-            hipLaunchKernelGGL(k_induce_scatter, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                               srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small);
+            if (remap)
+                hipLaunchKernelGGL(k_induce_scatter<true>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+            else
+                hipLaunchKernelGGL(k_induce_scatter<false>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_readback(ctx, ctx->d_small, 4));
@@ -778,6 +854,7 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
     uint64_t collapse_max = COLLAPSE_N < ctx->m_cap ? COLLAPSE_N : ctx->m_cap; // chain scratch: m_cap- and t_cap-sized arrays
     if (collapse_max > ctx->t_cap) collapse_max = ctx->t_cap;
 
+    const LmsRemap lms_rm{ctx->rm_fin, ctx->rm_pos, ctx->rm_E};
     // ---------------- L sweep: left to right ----------------
     Sweep L{ctx, d_SA, +1, {(int64_t)start[0], (int64_t)start[1], (int64_t)start[2], (int64_t)start[3]}};
     KTRY(run_pass(L, seed, seed + 1, 0, 1, 0xFu, -1, tot, &done));
@@ -799,7 +876,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
         KTRY(kiss_early_out(ctx, d_SA, c == 0 ? 0 : start[c], start[c] + cntL[c]));
         if (cntLMS[c]) {
             const uint32_t mask_gt = (0xFu << (c + 1)) & 0xFu; // S[v-1] > c for every LMS suffix
-            KTRY(run_pass(L, ctx->lmsP, ctx->lmsC, (int64_t)lms_start[c], cntLMS[c], mask_gt, -1, tot, &done));
+            if (ctx->lms_merged) KTRY(run_pass(L, ctx->lmsP, ctx->lmsC, (int64_t)lms_start[c], cntLMS[c], mask_gt, -1, tot, &done));
+            else KTRY(run_pass(L, ctx->lms_sorted_far, ctx->lms_ctx_far, (int64_t)lms_start[c], cntLMS[c], mask_gt, -1, tot, &done, &lms_rm));
         }
     }
 

@@ -105,6 +105,13 @@ struct kiss_hip_ctx {
     // near-end
     uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr, *near_tmp2 = nullptr; // place.hip: near_reserve
     uint64_t near_cap = 0;
+    // The induction reads the sorted far list in place plus this table of the near-end suffixes (induce.hip: LmsRemap);
+    // lmsP / lmsC are filled only on demand (kiss_merge_lms: stage outputs, KISS_HIP_MERGE_LMS=1)
+    bool lms_merged = false;
+    int near_form = 0;                    // 0: none, 1: pairwise ranks (text order), 2: merge-sorted
+    const uint32_t *near_sorted = nullptr; // form 2: the near-end suffixes in k-order
+    const uint32_t *rm_fin = nullptr, *rm_pos = nullptr;
+    uint32_t rm_E = 0;
 
     // host-pointer entry points: device-side copies of the caller's S / SA (allocated on first use, api.hip) and the
     // page-locked bounce buffers + streams of the staged transfers (xfer.hip)
@@ -185,6 +192,8 @@ constexpr int KISS_INTERNAL_TOO_DEEP = 1000; // never crosses the ABI
 int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, uint8_t *heads_in = nullptr);
 // isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)
 int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
+// fills ctx->lmsP / ctx->lmsC from the far list and the near-end ranks of the last kiss_place_lms
+int kiss_merge_lms(kiss_hip_ctx *ctx);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // host <-> device legs of the host-pointer entry points (xfer.hip); both return after the bytes have arrived

@@ -327,12 +327,34 @@ static int near_reserve(kiss_hip_ctx *ctx, uint64_t E)
     return KISS_HIP_OK;
 }
 
+namespace {
+// near-end suffixes by ascending merged index (E is small here: all pairs)
+__global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__restrict__ near_pos,
+                                                          const uint32_t *__restrict__ near_fin, uint32_t E,
+                                                          uint32_t *__restrict__ tab_fin, uint32_t *__restrict__ tab_pos)
+{
+    const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint32_t fe = near_fin[e];
+    uint32_t r = 0;
+    for (uint32_t f = 0; f < E; f++) r += near_fin[f] < fe ? 1u : 0u;
+    tab_fin[r] = fe;
+    tab_pos[r] = near_pos[e];
+}
+
+} // namespace
+
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 {
     (void)depth;
     const uint64_t m = ctx->m, m_far = ctx->m_far;
     const uint64_t E64 = m - m_far;
     ctx->stats.near_end = E64;
+    ctx->lms_merged = false;
+    ctx->near_form = 0;
+    ctx->near_sorted = nullptr;
+    ctx->rm_fin = ctx->rm_pos = nullptr;
+    ctx->rm_E = 0;
     if (m == 0) return KISS_HIP_OK;
     KTRY(near_reserve(ctx, E64 ? E64 : 1));
     const uint32_t E = (uint32_t)E64;
@@ -340,48 +362,82 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     // this size the merge-sort form takes over.  KISS_HIP_NEAR_MERGE_MIN (test hook) moves the switch.
     uint32_t merge_min = 4096;
     if (const char *ev = getenv("KISS_HIP_NEAR_MERGE_MIN")) merge_min = (uint32_t)strtoul(ev, nullptr, 10);
-    KTimer t(ctx, KISS_HIP_K_PLACE, m);
-    const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
-    if (E > 0 && E >= merge_min) {
-        // sort the near-end suffixes among themselves, then rank them against the far list
-        const uint32_t *cur = ctx->lms_pos + m_far; // ascending text positions = runs of length 1
-        uint32_t *bufs[2] = {ctx->near_pos, ctx->near_tmp};
-        int w = 0;
-        for (uint64_t run = 1; run < E; run *= 2) {
-            hipLaunchKernelGGL(k_near_merge_round, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                               cur, E, (uint32_t)run, bufs[w]);
-            cur = bufs[w];
-            w ^= 1;
+    {
+        KTimer t(ctx, KISS_HIP_K_PLACE, m);
+        const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
+        if (E > 0 && E >= merge_min) {
+            // sort the near-end suffixes among themselves, then rank them against the far list
+            const uint32_t *cur = ctx->lms_pos + m_far; // ascending text positions = runs of length 1
+            uint32_t *bufs[2] = {ctx->near_pos, ctx->near_tmp};
+            int w = 0;
+            for (uint64_t run = 1; run < E; run *= 2) {
+                hipLaunchKernelGGL(k_near_merge_round, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                                   cur, E, (uint32_t)run, bufs[w]);
+                cur = bufs[w];
+                w ^= 1;
+            }
+            const uint32_t *near_sorted = cur; // E == 1: the input itself
+            hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                               ctx->lms_sorted_far, m_far, near_sorted, E, ctx->near_idx);
+            hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
+            if (m_far && (uint64_t)k < n) {
+                hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
+                hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                                   ctx->lms_ctx_far);
+            }
+            ctx->near_form = 2;
+            ctx->near_sorted = near_sorted;
+            ctx->rm_fin = ctx->near_fin; // both lists are k-sorted: the merged indexes ascend already
+            ctx->rm_pos = near_sorted;
+        } else if (E > 0) {
+            const uint32_t *near_pos = ctx->lms_pos + m_far; // ascending list: the near-end suffixes are its tail
+            hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                               ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);
+            hipLaunchKernelGGL(k_near_order, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k, near_pos,
+                               ctx->near_idx, E, ctx->near_fin);
+            if (m_far && (uint64_t)k < n) {
+                hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
+                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
+                hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                                   ctx->lms_ctx_far);
+            }
+            // (stream order: k_near_tie_mark has read near_tmp2 before the table overwrites it)
+            hipLaunchKernelGGL(k_near_table, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, near_pos, ctx->near_fin, E, ctx->near_tmp,
+                               ctx->near_tmp2);
+            ctx->near_form = 1;
+            ctx->rm_fin = ctx->near_tmp;
+            ctx->rm_pos = ctx->near_tmp2;
         }
-        const uint32_t *near_sorted = cur; // E == 1: the input itself
-        hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                           ctx->lms_sorted_far, m_far, near_sorted, E, ctx->near_idx);
-        hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
-        if (m_far && (uint64_t)k < n) {
-            hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                               ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
-            hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                               ctx->lms_ctx_far);
-        }
-        if (m_far)
-            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0,
-                               ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_idx, E,
-                               ctx->lmsP, ctx->lmsC);
-        hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, near_sorted,
-                           ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
-    } else if (E > 0) {
-        const uint32_t *near_pos = ctx->lms_pos + m_far; // ascending list: the near-end suffixes are its tail
-        hipLaunchKernelGGL(k_near_rank, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
-                           ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);
-        hipLaunchKernelGGL(k_near_order, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
-                           ctx->pk, n, (uint64_t)k, near_pos, ctx->near_idx, E, ctx->near_fin);
-        if (m_far && (uint64_t)k < n) {
-            hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                               ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
-            hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                               ctx->lms_ctx_far);
-        }
+        ctx->rm_E = E;
         KCHECK(hipGetLastError());
+    }
+    static const bool merge_now = getenv("KISS_HIP_MERGE_LMS") != nullptr; // A-B hook: the merged copy of round 1
+    if (merge_now) KTRY(kiss_merge_lms(ctx));
+    return KISS_HIP_OK;
+}
+
+// The merged list as an array of its own (what `put_lms_suffix` writes into SA in the reference): only the stage
+// outputs of the tests and the A-B hook ask for it.
+int kiss_merge_lms(kiss_hip_ctx *ctx)
+{
+    if (ctx->lms_merged || ctx->m == 0) return KISS_HIP_OK;
+    const uint64_t m_far = ctx->m_far;
+    const uint32_t E = ctx->rm_E;
+    KTimer t(ctx, KISS_HIP_K_PLACE, ctx->m);
+    const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
+    const unsigned fgrid = (unsigned)div_up(div_up(m_far, 4), PL_THREADS);
+    if (E == 0) {
+        hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far,
+                           m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP, ctx->lmsC);
+    } else if (ctx->near_form == 2) {
+        if (m_far)
+            hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far,
+                               ctx->lms_ctx_far, m_far, ctx->near_idx, E, ctx->lmsP, ctx->lmsC);
+        hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->near_sorted, ctx->near_fin, E,
+                           ctx->lmsP, ctx->lmsC);
+    } else {
+        const uint32_t *near_pos = ctx->lms_pos + m_far;
         // sorted insertion indexes for the merge (E is tiny: sort on the host)
         std::vector<uint32_t> idx(E);
         KCHECK(hipMemcpyAsync(idx.data(), ctx->near_idx, E * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -390,16 +446,12 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         KCHECK(hipMemcpyAsync(ctx->near_pos, idx.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         KCHECK(hipStreamSynchronize(ctx->stream)); // idx goes out of scope
         if (m_far)
-            hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0,
-                               ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, ctx->near_pos, E,
-                               ctx->lmsP, ctx->lmsC);
-        hipLaunchKernelGGL(k_merge_near, dim3((unsigned)div_up(E, PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
-                           ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP, ctx->lmsC);
-    } else {
-        hipLaunchKernelGGL(k_merge_far, dim3((unsigned)div_up(div_up(m_far, 4), PL_THREADS)), dim3(PL_THREADS), 0, ctx->stream,
-                           ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far, m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP,
+            hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far,
+                               ctx->lms_ctx_far, m_far, ctx->near_pos, E, ctx->lmsP, ctx->lmsC);
+        hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP,
                            ctx->lmsC);
     }
     KCHECK(hipGetLastError());
+    ctx->lms_merged = true;
     return KISS_HIP_OK;
 }
