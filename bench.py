@@ -53,6 +53,8 @@ ALGO_BYTES = {
 }
 
 
+DOMINANT_CLASS = "radix_scatter"  # timed inside the timed region; bench checks it against the full breakdown
+
 # HBM traffic measured with rocprofv3 PMC passes (tools/pmc.sh; profiles/r02_pmc_fetch_n5e8.csv and
 # profiles/r02_pmc_write_tcc_n5e8.csv, round 1: r01_pmc_*; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
 # streaming reads) per algorithmic byte of the same launches (n = 5e8, 41 dispatches of k_radix_scatter<0,false,true>: the
@@ -423,6 +425,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_500_000_000,
                     help="bases of the CPU baseline sample (0 = skip); 1.5e9 bases = ~15 s of oracle/_ref time at 24 threads")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="time EVERY kernel class inside the timed region (two HIP events per launch, ~560 launches per "
+                         "sort: +3 ms per step); default: only the dominant class there, the others in --profile-steps "
+                         "extra steps after it")
+    ap.add_argument("--profile-steps", type=int, default=2,
+                    help="extra, untimed steps with every kernel class timed (the per-class breakdown of the line)")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: 'sharded' = ONE text, LMS sort sharded by key range over the ranks with an RCCL "
                          "all-to-all (strong scaling); 'replicas' = one independent text per rank (weak scaling)")
@@ -499,7 +507,12 @@ def main():
     SA = torch.empty(n + 1, dtype=torch.int32, device=device)  # u32 payload; torch has no uint32 arithmetic needs
     torch.cuda.synchronize()
 
-    ctx = kiss_amd.Context(max_n=n, device=local_rank, profiling=not args.no_profile)
+    ctx = kiss_amd.Context(max_n=n, device=local_rank)
+    # The contract wants the dominant kernel's launch duration from HIP events inside the timed region.  Events around
+    # every launch of every class cost ~5 us of stream time each; so the timed region times the dominant class only
+    # (DOMINANT_CLASS, checked against the full breakdown below) and the other classes are timed in extra steps.
+    if not args.no_profile:
+        ctx.set_profiling(True, None if args.profile_all else [DOMINANT_CLASS])
     stream = torch.cuda.current_stream().cuda_stream
 
     if sharded:
@@ -546,6 +559,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-class breakdown: every class timed, outside the timed region
+    prof_agg, prof_steps = agg, args.steps
+    if not args.no_profile and not args.profile_all and args.profile_steps > 0 and not sharded:
+        ctx.set_profiling(True)
+        prof_agg, prof_steps = {}, args.profile_steps
+        for _ in range(args.profile_steps):
+            step()
+            for name, v in ctx.stats()["kernels"].items():
+                a = prof_agg.setdefault(name, {"ms": 0.0, "launches": 0, "items": 0})
+                a["ms"] += v["ms"]
+                a["launches"] += v["launches"]
+                a["items"] += v["items"]
+        ctx.set_profiling(True, [DOMINANT_CLASS])
+        barrier()
+
     if rank == 0:
         total_bases = float(n) * args.steps * (1 if sharded else world)
         value = total_bases / elapsed
@@ -586,8 +614,11 @@ def main():
         # roofline of the dominant kernel class (live HIP-event timing inside the library)
         roof = None
         if agg and not args.no_profile:
-            dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-            name, a = dom
+            # the dominant class according to the full breakdown; its launch duration from the timed region's events
+            name = max(prof_agg.items(), key=lambda kv: kv[1]["ms"])[0]
+            in_timed_region = bool(agg.get(name, {}).get("launches"))
+            a = agg[name] if in_timed_region else prof_agg[name]
+            a_steps = args.steps if in_timed_region else prof_steps
             if a["launches"] and a["ms"] > 0:
                 bytes_per_launch = ALGO_BYTES.get(name, 0.0) * a["items"] / a["launches"]
                 avg_s = 1e-3 * a["ms"] / a["launches"]
@@ -598,9 +629,15 @@ def main():
                                     if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
                         "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
                                         "kernel (separate rocprofv3 --pmc runs, profiles/r02_pmc_*.csv)",
-                        "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / args.steps,
+                        "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / a_steps,
+                        "measured_in": ("timed region (HIP events around this class only)" if in_timed_region and
+                                        not args.profile_all else
+                                        "timed region (HIP events around every class)" if in_timed_region else
+                                        "profiled steps after the timed region (not the class timed inside it)"),
                         "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
-                        "kernel_ms_per_step": {kn: kv["ms"] / args.steps for kn, kv in agg.items() if kv["launches"]}}
+                        "kernel_ms_per_step": {kn: kv["ms"] / prof_steps for kn, kv in prof_agg.items() if kv["launches"]},
+                        "kernel_ms_per_step_from": ("timed region" if prof_agg is agg else
+                                                    "%d extra steps with every class timed" % prof_steps)}
         out["roofline"] = roof
         # whole-path algorithmic bytes: 0.25 n + 20 m + 16 (n+1) + 2 n
         m = last_stats["m"]

@@ -121,6 +121,9 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n);
 int kiss_hip_ctx_destroy(kiss_hip_ctx *ctx);
 /* enable/disable per-kernel HIP-event timing (adds event overhead; off by default) */
 int kiss_hip_ctx_set_profiling(kiss_hip_ctx *ctx, int enabled);
+/* the same for chosen kernel classes only: bit i of class_mask = class KISS_HIP_K_* number i.  A pair of events
+ * per launch costs a few microseconds of stream time; timing one class leaves the others back to back. */
+int kiss_hip_ctx_set_profiling_mask(kiss_hip_ctx *ctx, uint64_t class_mask);
 /* last hipError_t seen by this ctx (0 = hipSuccess) and its string */
 int kiss_hip_last_hip_error(const kiss_hip_ctx *ctx, const char **msg);
 int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out);

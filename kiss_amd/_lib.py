@@ -97,6 +97,7 @@ def load():
     lib.kiss_hip_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_uint64]
     lib.kiss_hip_ctx_destroy.argtypes = [vp]
     lib.kiss_hip_ctx_set_profiling.argtypes = [vp, ctypes.c_int]
+    lib.kiss_hip_ctx_set_profiling_mask.argtypes = [vp, ctypes.c_uint64]
     lib.kiss_hip_last_hip_error.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p)]
     lib.kiss_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     lib.kiss_hip_ctx_workspace_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
@@ -141,7 +142,7 @@ def load():
     for name in ("kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file",
                  "kiss_hip_copy_to_host", "kiss_hip_free_dev"):
         getattr(lib, name).restype = ctypes.c_int
-    for name in ("kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy", "kiss_hip_ctx_set_profiling",
+    for name in ("kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy", "kiss_hip_ctx_set_profiling", "kiss_hip_ctx_set_profiling_mask",
                  "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
                  "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32",
                  "kiss_hip_ctx_suffix_sort_dna_u32_dev", "kiss_hip_ctx_get_stage_outputs",
@@ -160,7 +161,7 @@ def strerror(status):
 # every symbol include/kiss_hip.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = [
     "kiss_hip_version", "kiss_hip_strerror", "kiss_hip_device_count", "kiss_hip_ctx_create", "kiss_hip_ctx_destroy",
-    "kiss_hip_ctx_set_profiling", "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
+    "kiss_hip_ctx_set_profiling", "kiss_hip_ctx_set_profiling_mask", "kiss_hip_last_hip_error", "kiss_hip_get_stats", "kiss_hip_ctx_workspace_bytes",
     "kiss_hip_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32", "kiss_hip_ctx_suffix_sort_dna_u32_dev",
     "kiss_hip_ctx_get_stage_outputs", "kiss_hip_ctx_verify_sa_dev", "kiss_hip_sa_digest_host", "kiss_hip_fnv1a64_host",
     "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",

@@ -12,7 +12,7 @@
 // ---- profiling timers ----------------------------------------------------------------
 KTimer::KTimer(kiss_hip_ctx *c, int cls, uint64_t items) : ctx(c), idx(-1)
 {
-    if (!ctx->profiling) return;
+    if (!((ctx->profile_mask >> cls) & 1ull)) return;
     if (ctx->ev_used == ctx->ev_pool.size()) {
         kiss_hip_ctx::Ev e;
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -491,7 +491,14 @@ int kiss_hip_ctx_destroy(kiss_hip_ctx *ctx)
 int kiss_hip_ctx_set_profiling(kiss_hip_ctx *ctx, int enabled)
 {
     if (!ctx) return KISS_HIP_E_INVALID;
-    ctx->profiling = enabled != 0;
+    ctx->profile_mask = enabled ? ~0ull : 0ull;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_ctx_set_profiling_mask(kiss_hip_ctx *ctx, uint64_t class_mask)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    ctx->profile_mask = class_mask;
     return KISS_HIP_OK;
 }
 

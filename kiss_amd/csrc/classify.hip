@@ -253,6 +253,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                                                         uint32_t *__restrict__ tile_cnt, // count: out; emit: offsets in
                                                         uint32_t *__restrict__ d_counts, uint64_t far_limit,
                                                         uint64_t win_lo, uint64_t win_hi, // only positions in [lo, hi)
+                                                        uint64_t tile_lo, uint64_t tile_hi, // = the tiles that overlap it
                                                         uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key,
                                                         uint32_t *__restrict__ ghist) // emit: round-0 digit histograms
 {
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
 #pragma unroll
     for (int i = 0; i < 13; i++) acc[i] = 0;
 
-    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    (void)tiles;
+    for (uint64_t tile = tile_lo + blockIdx.x; tile < tile_hi; tile += gridDim.x) {
         uint64_t w = tile * CL_THREADS + threadIdx.x;
         WordMasks m;
         if (w < words) m = word_masks(pk, w, n);
@@ -402,6 +404,13 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         if (depth > n) none_far = true;
         else far_limit = n - depth;
     }
+    // a rank of the sharded form classifies its window only: the count and emit kernels visit the tiles that overlap
+    // [win_lo, win_hi) (the carry fold in front of them still runs over the whole text: a type depends on what follows)
+    constexpr uint64_t TILE_BASES = (uint64_t)CL_THREADS * 32;
+    const uint64_t tile_lo = win_lo / TILE_BASES < tiles ? win_lo / TILE_BASES : tiles;
+    uint64_t tile_hi = div_up(win_hi, TILE_BASES) < tiles ? div_up(win_hi, TILE_BASES) : tiles;
+    if (tile_hi < tile_lo || win_hi <= win_lo) tile_hi = tile_lo;
+    const uint64_t wtiles = tile_hi - tile_lo;
     KTRY(kiss_zero_u32(ctx, ctx->d_counts, 16));
     {
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
@@ -417,13 +426,16 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         } else {
             hipLaunchKernelGGL(k_tile_cin, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_gp, tiles);
         }
-        unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
-        hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
-                           ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, (uint32_t *)nullptr,
-                           (uint64_t *)nullptr, (uint32_t *)nullptr);
+        if (wtiles) {
+            unsigned grid = (unsigned)(wtiles < 2048 ? wtiles : 2048);
+            hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
+                               ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, tile_lo, tile_hi,
+                               (uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+        }
         KCHECK(hipGetLastError());
     }
-    KTRY(kiss_scan_u32(ctx, ctx->tile_cnt, ctx->tile_cnt, tiles));
+    // offsets of the window's tiles into the emitted list (the list holds the window's LMS suffixes only)
+    if (wtiles) KTRY(kiss_scan_u32(ctx, ctx->tile_cnt + tile_lo, ctx->tile_cnt + tile_lo, wtiles));
     KTRY(kiss_readback(ctx, ctx->d_counts, 16));
     for (int i = 0; i < 12; i++) ctx->counts[i] = ctx->h_pinned[i];
     uint64_t m = (uint64_t)ctx->h_pinned[8] + ctx->h_pinned[9] + ctx->h_pinned[10] + ctx->h_pinned[11];
@@ -436,9 +448,9 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         const bool hist = ctx->rx_ghist && ctx->m_far > 1 && win_lo == 0 && win_hi == n;
         if (hist) KTRY(kiss_zero_u32(ctx, ctx->rx_ghist, 256ull * KISS_R0_PASSES));
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
-        const unsigned grid = (unsigned)(tiles < 8192 ? tiles : 8192);
+        const unsigned grid = (unsigned)(wtiles < 8192 ? wtiles : 8192);
         hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
-                           words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi,
+                           words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, tile_lo, tile_hi,
                            ctx->lms_pos, ctx->keyA, hist ? ctx->rx_ghist : (uint32_t *)nullptr);
         KCHECK(hipGetLastError());
         if (hist) ctx->rx_ghist_count = ctx->m_far; // consumed (or dropped) by the next kiss_radix_sort call

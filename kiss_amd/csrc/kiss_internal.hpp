@@ -134,7 +134,7 @@ struct kiss_hip_ctx {
     uint64_t n = 0, m = 0, m_far = 0;
     uint64_t counts[12] = {0};
     kiss_hip_stats stats{};
-    bool profiling = false;
+    uint64_t profile_mask = 0; // bit i: kernel class i is timed with a pair of HIP events per launch
     struct Ev { hipEvent_t a, b; int cls; };
     std::vector<Ev> ev_pool;
     size_t ev_used = 0;

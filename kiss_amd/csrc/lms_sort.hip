@@ -770,6 +770,158 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
     }
 }
 
+// ---- round 0 in ONE pass over the sorted keys ---------------------------------------------------------------------
+// k_fc0_count + scan + k_fc0_compact read the 7 GB of sorted keys twice.  Here a tile of FC1_TILE items flags its items,
+// publishes its (survivors, segment heads) pair, finds the sum over all earlier tiles by a decoupled look-back and
+// compacts -- the keys are read once.  One 64-bit descriptor per tile: [status:2 | survivors:31 | heads:31] (status 1 =
+// this tile's counts, 2 = counts of this and all earlier tiles); wave 0 inspects 64 predecessors per round trip.  Tiles
+// are numbered by an atomic ticket, so every predecessor of a running tile is running or done, and the wait is bounded
+// like the radix look-back (radix.hip) -- an error flag instead of a hung GPU.  The host learns the totals only
+// afterwards, so stores beyond `cap` (the tied-segment arrays) are dropped; the caller regrows and runs the pass again.
+constexpr int FC1_THREADS = 1024;
+constexpr int FC1_TILE = FC1_THREADS * FC_ITEMS; // 8192
+constexpr uint32_t FC1_SPIN_LIMIT = 1u << 22;
+
+__global__ __launch_bounds__(FC1_THREADS) void k_fc0_onepass(const uint64_t *__restrict__ key,
+                                                            const uint32_t *__restrict__ pos, uint64_t count,
+                                                            int cmp_shift, uint64_t tiles, uint64_t *__restrict__ desc,
+                                                            uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
+                                                            uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
+                                                            uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
+                                                            uint32_t *__restrict__ octx, uint32_t *__restrict__ nctx,
+                                                            uint64_t cap, uint64_t *__restrict__ total)
+{
+    __shared__ uint32_t ws[FC1_THREADS / 64][2];
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_excl[2];
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint64_t tile = s_tile;
+    if (tile >= tiles) return;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id();
+    const uint64_t i0 = (tile * FC1_THREADS + threadIdx.x) * FC_ITEMS;
+    uint64_t k[FC_ITEMS + 2];
+    uint32_t valid, sm, hm;
+    uint32_t p[FC_ITEMS], cw[FC_ITEMS];
+    fc0_load(key, i0, count, cmp_shift, k, valid, cw);
+    fc0_flags(k, i0, count, valid, sm, hm);
+    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+    uint32_t is = ns, ih = nh; // inclusive wave prefixes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
+        if ((int)lane >= d) {
+            is += os;
+            ih += oh;
+        }
+    }
+    if (lane == 63) {
+        ws[wave][0] = is;
+        ws[wave][1] = ih;
+    }
+    // the positions are not needed before the offsets are known: their loads overlap the look-back
+    if (valid == FC_ITEMS) {
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 4; q++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(pos + i0 + 4 * q);
+            p[4 * q] = t.x;
+            p[4 * q + 1] = t.y;
+            p[4 * q + 2] = t.z;
+            p[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++) p[e] = (uint32_t)e < valid ? pos[i0 + e] : 0u;
+    }
+    __syncthreads();
+    uint32_t ts = 0, th = 0, ws0 = 0, wh0 = 0; // tile totals; totals of the waves before mine
+#pragma unroll
+    for (int w = 0; w < FC1_THREADS / 64; w++) {
+        if (w < wave) {
+            ws0 += ws[w][0];
+            wh0 += ws[w][1];
+        }
+        ts += ws[w][0];
+        th += ws[w][1];
+    }
+    if (wave == 0) {
+        constexpr uint64_t M31 = 0x7FFFFFFFull;
+        const uint64_t mine = ((uint64_t)ts << 31) | (uint64_t)th;
+        uint64_t es = 0, eh = 0; // survivors / heads in all earlier tiles
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(&desc[0], (2ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&desc[tile], (1ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t base = (int64_t)tile;
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t t = base - 1 - (int64_t)lane;
+                const uint64_t v = t >= 0 ? __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : (2ull << 62); // in front of tile 0: nothing
+                const uint32_t st = (uint32_t)(v >> 62);
+                const uint64_t incl = __ballot(st == 2u), ready = __ballot(st != 0u);
+                const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;      // nearest running total
+                const uint64_t need = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0 .. first
+                if ((ready & need) != need) { // a predecessor this side of it has not published yet
+                    if (++spins > FC1_SPIN_LIMIT) {
+                        if (lane == 0) *err = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t a = lane <= first ? (v >> 31) & M31 : 0ull, b = lane <= first ? v & M31 : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    a += __shfl_xor(a, d, 64);
+                    b += __shfl_xor(b, d, 64);
+                }
+                es += a;
+                eh += b;
+                if (first < 64u) break;
+                base -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&desc[tile], (2ull << 62) | ((es + ts) << 31) | (eh + th), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl[0] = (uint32_t)es;
+            s_excl[1] = (uint32_t)eh;
+            if (tile + 1 == tiles) total[0] = ((es + ts) << 32) | (eh + th);
+        }
+    }
+    __syncthreads();
+    if (valid == 0) return;
+    uint32_t bs = s_excl[0] + ws0 + (is - ns), bh = s_excl[1] + wh0 + (ih - nh);
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((sm >> e) & 1u) {
+            const uint32_t ni = bs++;
+            if ((hm >> e) & 1u) bh++;
+            const uint32_t sid = bh - 1u; // heads up to and including this item's own segment head
+            if (ni < cap) {
+                npos[ni] = p[e];
+                nslot[ni] = (uint32_t)(i0 + e);
+                nseg[ni] = sid;
+                if ((hm >> e) & 1u) nsegstart[sid] = ni;
+                if (nctx) nctx[ni] = cw[e]; // travels with the tied item through the first refinement round
+            }
+            cw[e] = 0; // tied so far: written when the item is finished, else gathered at placement
+        }
+    }
+    if (valid == FC_ITEMS) {
+#pragma unroll
+        for (int q = 0; q < FC_ITEMS / 4; q++)
+            *reinterpret_cast<uint4 *>(octx + i0 + 4 * q) = make_uint4(cw[4 * q], cw[4 * q + 1], cw[4 * q + 2], cw[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < FC_ITEMS; e++)
+            if ((uint32_t)e < valid) octx[i0 + e] = cw[e];
+    }
+}
+
 // ---- tie flags as bytes (the doubling phase's first compaction over all n + 1 suffixes): 8 flags per load, and the
 // suffix array is read only for the few entries that are tied ------------------------------------------------
 __device__ __forceinline__ void fch_flags(const uint8_t *__restrict__ hb, uint64_t i0, uint64_t count, uint32_t &valid,
@@ -1044,19 +1196,47 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     ctx->stats.sort_item_rounds += count;
     uint32_t *Pc = rb.pos[res ^ 1]; // receives the survivors' positions
     uint64_t tot;
-    KTRY((fc_count<FC_KEY>(ctx, rb.key[res], nullptr, count, r0_shift, 0, d_total)));
-    KTRY(fc_read_total(ctx, d_total, &tot));
-    if ((tot >> 32) > ctx->t_cap) { // more tied suffixes than the tied-segment arrays hold: regrow them (empty so far)
-        const uint64_t surv = tot >> 32;
-        KTRY(kiss_tied_reserve(ctx, surv + surv / 8 + 1024));
+    bool have_tctx = false; // bslot is free until the big-segment path of the first round: the tied items' context words
+    const bool no_onepass = getenv("KISS_HIP_NO_FC0_ONEPASS") != nullptr; // A-B hook: count + scan + compact
+    const uint64_t tiles1 = div_up(count, FC1_TILE);
+    // (the result of the five passes is in buffer 1 = the output list itself, so there are no positions to copy)
+    const bool onepass = !no_onepass && ctx->rx_desc && tiles1 >= 8 && tiles1 + 1 <= 256 * ctx->rx_tiles_cap &&
+                         rb.pos[res] == ctx->lms_sorted_far;
+    if (onepass) {
+        uint64_t *desc = ctx->rx_desc; // the radix sort is done with it; its passes tell stale entries by their tags
+        uint32_t *ticket = reinterpret_cast<uint32_t *>(desc + tiles1);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            KTRY(kiss_zero_u32(ctx, desc, 2 * tiles1 + 2));
+            {
+                KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+                hipLaunchKernelGGL(k_fc0_onepass, dim3((unsigned)tiles1), dim3(FC1_THREADS), 0, ctx->stream, rb.key[res], rb.pos[res],
+                                   count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
+                                   ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
+                KCHECK(hipGetLastError());
+            }
+            KTRY(fc_read_total(ctx, d_total, &tot));
+            if ((tot >> 32) <= ctx->t_cap) break;
+            if (attempt) return KINTERNAL();
+            // more tied suffixes than the tied-segment arrays hold (their stores were dropped): regrow, once more
+            const uint64_t surv = tot >> 32;
+            KTRY(kiss_tied_reserve(ctx, surv + surv / 8 + 1024));
+        }
+        have_tctx = true;
+    } else {
         KTRY((fc_count<FC_KEY>(ctx, rb.key[res], nullptr, count, r0_shift, 0, d_total)));
+        KTRY(fc_read_total(ctx, d_total, &tot));
+        if ((tot >> 32) > ctx->t_cap) { // more tied suffixes than the tied-segment arrays hold: regrow them (empty so far)
+            const uint64_t surv = tot >> 32;
+            KTRY(kiss_tied_reserve(ctx, surv + surv / 8 + 1024));
+            KTRY((fc_count<FC_KEY>(ctx, rb.key[res], nullptr, count, r0_shift, 0, d_total)));
+        }
     }
     uint32_t *Sc = ctx->slotA, *Gc = ctx->segA, *SSc = ctx->segstartA;
     uint64_t *F1 = ctx->flags;
     uint64_t *F2 = ctx->flags + ctx->t_cap;
-    bool have_tctx = false; // bslot is free until the big-segment path of the first round: the tied items' context words
-    KTRY((fc_compact<FC_KEY, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
-                                   ctx->lms_sorted_far, nullptr, ctx->lms_ctx_far, ctx->bslot, &have_tctx)));
+    if (!onepass)
+        KTRY((fc_compact<FC_KEY, false>(ctx, rb.key[res], nullptr, rb.pos[res], nullptr, count, r0_shift, 0, Pc, Sc, Gc, SSc,
+                                       ctx->lms_sorted_far, nullptr, ctx->lms_ctx_far, ctx->bslot, &have_tctx)));
     count = tot >> 32;
     uint64_t nseg = tot & 0xFFFFFFFFull;
     if (dbg)

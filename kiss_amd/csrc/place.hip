@@ -412,7 +412,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         ctx->rm_E = E;
         KCHECK(hipGetLastError());
     }
-    static const bool merge_now = getenv("KISS_HIP_MERGE_LMS") != nullptr; // A-B hook: the merged copy of round 1
+    const bool merge_now = getenv("KISS_HIP_MERGE_LMS") != nullptr; // A-B hook: the merged copy of round 1
     if (merge_now) KTRY(kiss_merge_lms(ctx));
     return KISS_HIP_OK;
 }

@@ -81,8 +81,15 @@ class Context:
             self.free_dev(ptr)
         return out
 
-    def set_profiling(self, on):
-        _check(self._lib.kiss_hip_ctx_set_profiling(self._ctx, 1 if on else 0), "kiss_hip_ctx_set_profiling")
+    def set_profiling(self, on, classes=None):
+        """per-kernel HIP-event timing: all classes, or only the named ones (_lib.KERNEL_CLASSES)"""
+        if on and classes is not None:
+            mask = 0
+            for c in classes:
+                mask |= 1 << _lib.KERNEL_CLASSES.index(c)
+            _check(self._lib.kiss_hip_ctx_set_profiling_mask(self._ctx, mask), "kiss_hip_ctx_set_profiling_mask")
+        else:
+            _check(self._lib.kiss_hip_ctx_set_profiling(self._ctx, 1 if on else 0), "kiss_hip_ctx_set_profiling")
 
     def workspace_bytes(self):
         v = ctypes.c_uint64()

@@ -42,6 +42,9 @@ def test_bench_single_gpu_line():
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # only the dominant class is timed inside the timed region; the line says where each figure was measured
+    assert r["measured_in"].startswith(("timed region", "profiled steps")) and r["kernel_ms_per_step"]
+    assert len(r["kernel_ms_per_step"]) > 3 and "extra steps" in r["kernel_ms_per_step_from"]
     c = out["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 

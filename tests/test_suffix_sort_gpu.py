@@ -266,6 +266,27 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("hook", ["KISS_HIP_NO_FC0_ONEPASS", "KISS_HIP_MERGE_LMS"])
+def test_round2_shortcuts_equal_the_forms_they_replace(ctx, oracle, monkeypatch, hook):
+    # KISS_HIP_NO_FC0_ONEPASS: round 0 flags + compacts with count / scan / compact instead of the one-pass look-back;
+    # KISS_HIP_MERGE_LMS: the induction reads a merged copy of the LMS list instead of far list + near-end table.
+    # Both forms must give the oracle's SA; with the tied-segment arrays too small for the first attempt as well
+    # (the one-pass form learns the survivor count only afterwards and runs again).
+    S = gen.genome_like(3_000_000, 31)
+    want = oracle.suffix_sort(S, 256)
+    assert np.array_equal(ctx.suffix_sort(S, 256), want)
+    monkeypatch.setenv(hook, "1")
+    assert np.array_equal(ctx.suffix_sort(S, 256), want)
+    monkeypatch.delenv(hook)
+    import kiss_amd
+    rep = np.tile(gen.iid(3000, 5), 700)          # every LMS suffix tied after round 0: more than the default t_cap
+    c = kiss_amd.Context(max_n=rep.size, device=0)
+    try:
+        assert np.array_equal(c.suffix_sort(rep, 256), oracle.suffix_sort(rep, 256))
+    finally:
+        c.close()
+
+
 def _random_text(rng, n):
     """small adversarial texts: mixtures of i.i.d. stretches, runs, tandem repeats and copies of earlier pieces"""
     out = []
