@@ -131,7 +131,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
     void **ptrs[] = {(void **)&ctx->lms_pos, (void **)&ctx->keyA, (void **)&ctx->keyB, (void **)&ctx->posA,
                      (void **)&ctx->posB, (void **)&ctx->lms_sorted_far, (void **)&ctx->lms_ctx_far,
                      (void **)&ctx->lmsP, (void **)&ctx->lmsC, (void **)&ctx->tile_hist, (void **)&ctx->scan_tmp,
-                     (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist};
+                     (void **)&ctx->rx_desc, (void **)&ctx->rx_ghist, (void **)&ctx->fc_desc};
     for (void **p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -322,6 +322,8 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
         ctx->rx_tiles_cap = m_cap / 16384 + 2;
         ALLOC(rx_desc, 256 * ctx->rx_tiles_cap);
         ALLOC(rx_ghist, 256 * 12);
+        ctx->fc_desc_cap = m_cap / 8192 + 4;
+        ALLOC(fc_desc, ctx->fc_desc_cap);
 #undef ALLOC
         // descriptors carry the epoch of the pass that wrote them: cleared once, never again (the epoch keeps counting)
         if (hipMemset(ctx->rx_desc, 0, 256 * ctx->rx_tiles_cap * sizeof(uint64_t)) != hipSuccess) rc = KISS_HIP_E_HIP;

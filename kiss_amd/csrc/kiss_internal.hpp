@@ -80,6 +80,8 @@ struct kiss_hip_ctx {
     uint32_t *rx_ghist = nullptr, *rx_ctl = nullptr;
     uint64_t rx_ghist_count = 0; // != 0: rx_ghist already holds the round-0 digit counts of that many keys (classify.hip)
     uint64_t rx_tiles_cap = 0, rx_epoch = 0;
+    uint64_t *fc_desc = nullptr;  // round 0 flag + compact in one pass: one descriptor per 8192-item tile (+ ticket)
+    uint64_t fc_desc_cap = 0;
     uint32_t rx_ticket_base = 0;
     uint64_t *scan_tmp = nullptr;  // block sums for scans
     uint64_t scan_tmp_cap = 0;

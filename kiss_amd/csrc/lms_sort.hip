@@ -1200,10 +1200,10 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     const bool no_onepass = getenv("KISS_HIP_NO_FC0_ONEPASS") != nullptr; // A-B hook: count + scan + compact
     const uint64_t tiles1 = div_up(count, FC1_TILE);
     // (the result of the five passes is in buffer 1 = the output list itself, so there are no positions to copy)
-    const bool onepass = !no_onepass && ctx->rx_desc && tiles1 >= 8 && tiles1 + 1 <= 256 * ctx->rx_tiles_cap &&
+    const bool onepass = !no_onepass && ctx->fc_desc && tiles1 >= 8 && tiles1 + 1 <= ctx->fc_desc_cap &&
                          rb.pos[res] == ctx->lms_sorted_far;
     if (onepass) {
-        uint64_t *desc = ctx->rx_desc; // the radix sort is done with it; its passes tell stale entries by their tags
+        uint64_t *desc = ctx->fc_desc;
         uint32_t *ticket = reinterpret_cast<uint32_t *>(desc + tiles1);
         for (int attempt = 0; attempt < 2; attempt++) {
             KTRY(kiss_zero_u32(ctx, desc, 2 * tiles1 + 2));

@@ -6,5 +6,5 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 cd $root/kiss_amd/csrc
 make 2>&1 | grep -E "error|warning" || true
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result -DRX_PROF $EXTRA -c radix.hip -o /tmp/radix_prof.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libkiss_prof.so.bin api.o scan.o classify.o /tmp/radix_prof.o lms_sort.o isa.o place.o induce.o fm.o stages.o fasta.o general.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libkiss_prof.so.bin api.o scan.o classify.o /tmp/radix_prof.o lms_sort.o isa.o place.o induce.o fm.o stages.o fasta.o general.o verify.o xfer.o
 ls -la ../libkiss_prof.so.bin ../libkiss_hip.so
