@@ -59,6 +59,23 @@ __device__ __forceinline__ uint32_t remap_below(const LmsRemap &rm, uint64_t j) 
     return lo;
 }
 
+// the same for an index that is the same in every lane of the calling wave (all lanes must call): the table is compared
+// 64 entries at a time instead of by a chain of dependent loads per lane -- the count and scatter passes ask this twice per
+// tile of 2048 items, and with the binary search those two questions cost more than the tile itself
+__device__ __forceinline__ uint32_t remap_below_wave(const LmsRemap &rm, uint64_t j)
+{
+    if (rm.E > 256u) return remap_below(rm, j); // (a k in the hundred thousands: rare, and the search is uniform)
+    uint32_t cnt = 0;
+    for (uint32_t base = 0; base < rm.E; base += 64u) {
+        const uint32_t i = base + lane_id();
+        const bool lt = i < rm.E && (uint64_t)rm.fin[i] < j;
+        const uint32_t c = (uint32_t)__popcll(__ballot(lt));
+        cnt += c;
+        if (c < 64u) break; // the table ascends
+    }
+    return cnt;
+}
+
 // class of a source item: 0..3 = append v-1 to bucket of that base, 4 = nothing to append.
 // A word without bases (KISS_EMPTY_CTX: run empty; 0: a far LMS suffix that left the sort without one) is gathered
 // from the text and kept.  REMAP: idx is an index into the merged LMS list (see LmsRemap), else a physical one.
@@ -140,9 +157,9 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     // consecutive entries of the far list, `shift` entries below their merged index
     int64_t shift = 0;
     bool block = t0 + IN_TILE <= N;
-    if (REMAP && block) {
-        const uint32_t b0 = remap_below(rm, (uint64_t)beg + t0);
-        block = b0 == remap_below(rm, (uint64_t)beg + t0 + IN_TILE);
+    if (REMAP && block) { // (t0 is the same in all lanes of the wave)
+        const uint32_t b0 = remap_below_wave(rm, (uint64_t)beg + t0);
+        block = b0 == remap_below_wave(rm, (uint64_t)beg + t0 + IN_TILE);
         shift = (int64_t)b0;
     }
     if (block) {
@@ -206,10 +223,17 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
     uint32_t cnt[4] = {0, 0, 0, 0};
     int64_t shift = 0; // REMAP (dir > 0 only): see k_induce_count
     bool block = i0 + IN_ITEMS <= N;
-    if (REMAP && block) {
-        const uint32_t b0 = remap_below(rm, (uint64_t)beg + i0);
-        block = b0 == remap_below(rm, (uint64_t)beg + i0 + IN_ITEMS);
-        shift = (int64_t)b0;
+    if (REMAP) {
+        // first for the whole tile (one answer per wave, no dependent loads); only a tile that holds a near-end suffix
+        // asks per thread
+        const uint64_t tj = (uint64_t)beg + (uint64_t)blockIdx.x * IN_TILE;
+        const uint32_t t0 = remap_below_wave(rm, tj), t1 = remap_below_wave(rm, tj + IN_TILE);
+        if (t0 == t1) shift = (int64_t)t0;
+        else if (block) {
+            const uint32_t b0 = remap_below(rm, (uint64_t)beg + i0);
+            block = b0 == remap_below(rm, (uint64_t)beg + i0 + IN_ITEMS);
+            shift = (int64_t)b0;
+        }
     }
     if (block) {
         const int64_t p0 = (dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1)) - shift; // lowest address of my items
