@@ -287,6 +287,32 @@ def test_round2_shortcuts_equal_the_forms_they_replace(ctx, oracle, monkeypatch,
         c.close()
 
 
+def test_kernel_class_timing_can_be_limited_to_chosen_classes(oracle):
+    # kiss_hip_ctx_set_profiling_mask: HIP events only around the launches of the named classes (what bench.py does for the
+    # dominant kernel inside its timed region); the result does not depend on what is timed
+    import kiss_amd
+    S = gen.genome_like(1_500_000, 9)
+    want = oracle.suffix_sort(S, 256)
+    c = kiss_amd.Context(max_n=S.size, device=0)
+    try:
+        assert np.array_equal(c.suffix_sort(S, 256), want)
+        assert all(v["launches"] == 0 for v in c.stats()["kernels"].values())          # off by default
+        c.set_profiling(True, ["radix_scatter"])
+        assert np.array_equal(c.suffix_sort(S, 256), want)
+        k = c.stats()["kernels"]
+        assert k["radix_scatter"]["launches"] > 0 and k["radix_scatter"]["ms"] > 0
+        assert all(v["launches"] == 0 for name, v in k.items() if name != "radix_scatter")
+        c.set_profiling(True)
+        assert np.array_equal(c.suffix_sort(S, 256), want)
+        k = c.stats()["kernels"]
+        assert sum(1 for v in k.values() if v["launches"] > 0) >= 8
+        c.set_profiling(False)
+        c.suffix_sort(S, 256)
+        assert all(v["launches"] == 0 for v in c.stats()["kernels"].values())
+    finally:
+        c.close()
+
+
 def _random_text(rng, n):
     """small adversarial texts: mixtures of i.i.d. stretches, runs, tandem repeats and copies of earlier pieces"""
     out = []
