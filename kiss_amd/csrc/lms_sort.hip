@@ -1704,7 +1704,20 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     uint32_t *isa = ctx->CTX; // the induction's context words are dead by now: (n + 2) u32
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     uint8_t *heads = heads_in;
-    if (!heads) KCHECK(hipMalloc((void **)&heads, total));
+    if (!heads) { // one byte per suffix-array entry, kept by the ctx between calls (sized for max_n like pairs1 / pairs2)
+        if (!ctx->refine_heads) {
+            const uint64_t cap = ctx->max_n + 2;
+            hipError_t e = hipMalloc((void **)&ctx->refine_heads, cap);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->refine_heads = nullptr;
+                ctx->last_hip_error = (int)e;
+                return KISS_HIP_E_NOMEM;
+            }
+            ctx->ws_bytes += cap;
+        }
+        heads = ctx->refine_heads;
+    }
     int rc = KISS_HIP_OK;
     do {
         if (!heads_in) {
@@ -1862,6 +1875,6 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
         ctx->last_hip_error = (int)e;
         rc = KISS_HIP_E_HIP;
     }
-    if (!heads_in) (void)hipFree(heads);
+
     return rc;
 }
