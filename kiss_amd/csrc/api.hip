@@ -145,7 +145,7 @@ void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
     void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
-                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->near_tmp2, ctx->pairs1, ctx->pairs2, ctx->rx_ctl, ctx->refine_heads};
+                    ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->near_tmp2, ctx->pairs1, ctx->pairs2, ctx->rx_ctl, ctx->refine_heads, ctx->ga_codes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : ctx->fm_pool)

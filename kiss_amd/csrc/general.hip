@@ -13,6 +13,7 @@
 //   SA[0] = n, SA[1 + i] = sorted position i, group heads where the key changes;
 //   rank doubling from h = 7 on the tied suffixes (lms_sort.hip: kiss_exact_refine with the heads given).
 #include "kiss_internal.hpp"
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -49,6 +50,55 @@ __global__ __launch_bounds__(GA_THREADS) void k_ga_place(const uint64_t *__restr
     heads[1 + i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
 }
 
+// ---- texts over at most four distinct byte values (e.g. the reference's own 'A'..'D' test texts, tests/kiss.cpp) ----
+// A 7-character key holds only 14 bits of information there, so every suffix would go into the doubling rounds
+// (3.3 Gbytes/s); mapped to codes 0..3 in value order, the text is a DNA text and the induced-sorting path orders it
+// (exact order through PREFIX_DOUBLING: the same suffix array, four times as fast).
+// which byte values occur: out[0..7] = 256-bit set, out[8] = 1 as soon as a wave has seen more than four of them (every
+// wave stops at its next step then: a text over a large alphabet costs a few microseconds)
+__global__ __launch_bounds__(GA_THREADS) void k_ga_presence(const uint8_t *__restrict__ S, uint64_t n, uint32_t *__restrict__ out)
+{
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // the same in every lane of the wave
+    const uint64_t waves = (uint64_t)gridDim.x * (GA_THREADS / 64);
+    const uint64_t wave = (uint64_t)blockIdx.x * (GA_THREADS / 64) + (threadIdx.x >> 6);
+    volatile uint32_t *many = out + 8;
+    for (uint64_t base = wave * 64; base < n; base += waves * 64) {
+        if (*many) return;
+        const uint64_t i = base + lane_id();
+        const bool valid = i < n;
+        const uint32_t b = valid ? S[i] : 0u;
+        uint64_t todo = __ballot(valid);
+        while (todo) {
+            const uint32_t b0 = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(todo), 64);
+#pragma unroll
+            for (int w = 0; w < 8; w++) m[w] |= (uint32_t)w == (b0 >> 5) ? 1u << (b0 & 31u) : 0u;
+            todo &= ~__ballot(b == b0);
+        }
+        uint32_t distinct = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) distinct += (uint32_t)__popc(m[w]);
+        if (distinct > 4u) {
+            if (lane_id() == 0) *many = 1u;
+            return;
+        }
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+            if (m[w]) atomicOr(&out[w], m[w]);
+    }
+}
+
+// code = rank of the byte among the (at most four) values that occur, v1 < v2 < v3 being the larger ones
+__global__ __launch_bounds__(GA_THREADS) void k_ga_remap(const uint8_t *__restrict__ S, uint64_t n, uint32_t v1, uint32_t v2,
+                                                        uint32_t v3, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * GA_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = S[i];
+    out[i] = (uint8_t)((b >= v1 ? 1u : 0u) + (b >= v2 ? 1u : 0u) + (b >= v3 ? 1u : 0u));
+}
+
 } // namespace
 
 extern "C" {
@@ -69,6 +119,49 @@ int kiss_hip_ctx_suffix_sort_u8_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint6
         KTRY(kiss_zero_u32(ctx, d_SA, 1));
         KCHECK(hipStreamSynchronize(ctx->stream));
         return KISS_HIP_OK;
+    }
+    if (n >= 4096 && !getenv("KISS_HIP_NO_SMALL_ALPHABET")) { // at most four distinct byte values: the DNA path
+        uint32_t *d_set = ctx->d_small + 48; // 9 words
+        KTRY(kiss_zero_u32(ctx, d_set, 9));
+        const uint64_t blocks = div_up(n, 64ull * (GA_THREADS / 64) * 64); // ~64 steps per wave
+        hipLaunchKernelGGL(k_ga_presence, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(GA_THREADS), 0, ctx->stream, d_S, n,
+                           d_set);
+        KCHECK(hipGetLastError());
+        KTRY(kiss_readback(ctx, d_set, 9));
+        uint32_t vals[4], nv = 0;
+        bool small = ctx->h_pinned[8] == 0;
+        for (uint32_t v = 0; v < 256 && small; v++)
+            if ((ctx->h_pinned[v >> 5] >> (v & 31u)) & 1u) {
+                if (nv == 4) small = false;
+                else vals[nv++] = v;
+            }
+        if (small && nv >= 1) {
+            if (!ctx->ga_codes || ctx->ga_codes_cap < n) {
+                if (ctx->ga_codes) {
+                    (void)hipFree(ctx->ga_codes);
+                    ctx->ws_bytes -= ctx->ga_codes_cap;
+                    ctx->ga_codes = nullptr;
+                    ctx->ga_codes_cap = 0;
+                }
+                hipError_t e = hipMalloc((void **)&ctx->ga_codes, ctx->max_n);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->last_hip_error = (int)e;
+                    return KISS_HIP_E_NOMEM;
+                }
+                ctx->ga_codes_cap = ctx->max_n;
+                ctx->ws_bytes += ctx->max_n;
+            }
+            while (nv < 4) { // absent ranks: never reached by a byte of the text
+                vals[nv] = 256;
+                nv++;
+            }
+            hipLaunchKernelGGL(k_ga_remap, dim3((unsigned)div_up(n, GA_THREADS)), dim3(GA_THREADS), 0, ctx->stream, d_S, n, vals[1],
+                               vals[2], vals[3], ctx->ga_codes);
+            KCHECK(hipGetLastError());
+            return kiss_hip_ctx_suffix_sort_dna_u32_dev(ctx, ctx->ga_codes, n, 0xFFFFFFFFu, KISS_HIP_ALGO_PREFIX_DOUBLING, d_SA,
+                                                        (void *)ctx->stream);
+        }
     }
     // every position is an item here: the per-LMS arrays have to hold n of them
     if (n + 2 > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, n + n / 64 + 1024));

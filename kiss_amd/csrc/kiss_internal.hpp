@@ -109,6 +109,8 @@ struct kiss_hip_ctx {
     uint64_t near_cap = 0;
     // The induction reads the sorted far list in place plus this table of the near-end suffixes (induce.hip: LmsRemap);
     // lmsP / lmsC are filled only on demand (kiss_merge_lms: stage outputs, KISS_HIP_MERGE_LMS=1)
+    uint8_t *ga_codes = nullptr;     // general.hip: a byte text over <= 4 values, mapped to codes 0..3 (on first use)
+    uint64_t ga_codes_cap = 0;
     uint8_t *refine_heads = nullptr; // exact-order finish: tie flags, one byte per SA entry (allocated on first use)
     bool lms_merged = false;
     int near_form = 0;                    // 0: none, 1: pairwise ranks (text order), 2: merge-sorted

@@ -67,3 +67,19 @@ def test_large_texts_are_suffix_arrays(oracle, kind):
     assert is_suffix_array(S, sa)
     if kind == "dna":  # the byte path and the DNA paths agree (codes 0..3 are bytes too)
         assert np.array_equal(sa, oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED))
+
+
+@pytest.mark.parametrize("values", [b"ABCD", b"ACT", b"\x00\xff", b"z", b"\x05\x06\x07\x08"])
+def test_texts_over_at_most_four_values_take_the_dna_path(oracle, monkeypatch, values):
+    # general.hip maps such a text to codes 0..3 in value order and sorts it as DNA (exact order); the answer is the
+    # one the 7-character path gives (KISS_HIP_NO_SMALL_ALPHABET=1) and the oracle's exact suffix array of the codes
+    import kiss_amd
+    codes = gen.genome_like(300_000, 3) % len(values) if len(values) > 1 else np.zeros(20_000, np.uint8)
+    if codes.size > 60_000:
+        codes[1000:1600] = codes[50_000:50_600]  # a copy longer than any key
+    text = np.frombuffer(values, np.uint8)[codes]
+    sa = kiss_amd.suffix_array_bytes(text.tobytes())
+    assert is_suffix_array(text, sa)
+    assert np.array_equal(sa, oracle.suffix_sort(codes.astype(np.uint8), 0xFFFFFFFF))
+    monkeypatch.setenv("KISS_HIP_NO_SMALL_ALPHABET", "1")
+    assert np.array_equal(kiss_amd.suffix_array_bytes(text.tobytes()), sa)
