@@ -130,9 +130,9 @@ struct kiss_hip_ctx {
     std::vector<hipEvent_t> early_events;
     size_t early_used = 0;
     uint64_t early_bytes = 0;
-    void *xf_pin[8][2] = {};
-    hipEvent_t xf_done[8][2] = {};
-    hipStream_t xf_stream[8] = {};
+    void *xf_pin[16][2] = {};
+    hipEvent_t xf_done[16][2] = {};
+    hipStream_t xf_stream[16] = {};
     bool xf_ready = false;
 
     // state of the last call (for stage outputs / stats)

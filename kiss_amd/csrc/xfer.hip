@@ -11,13 +11,25 @@
 // Nothing here computes: bytes are moved as they are.
 #include "kiss_internal.hpp"
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
 
 namespace {
 
-constexpr int XF_THREADS = 8;
+constexpr int XF_MAX_THREADS = 16;
+// copy threads for pageable memory (each with two bounce buffers and a stream): KISS_HIP_XFER_THREADS, default 8
+static int xf_threads()
+{
+    static const int t = [] {
+        const char *e = getenv("KISS_HIP_XFER_THREADS");
+        const int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > XF_MAX_THREADS ? XF_MAX_THREADS : v);
+    }();
+    return t;
+}
+#define XF_THREADS xf_threads()
 constexpr size_t XF_CHUNK = 16ull << 20;
 
 bool host_is_pinned(const void *p)
@@ -160,7 +172,7 @@ void kiss_xfer_free(kiss_hip_ctx *ctx)
     ctx->early_events.clear();
     if (ctx->early_stream) (void)hipStreamDestroy(ctx->early_stream);
     ctx->early_stream = nullptr;
-    for (int t = 0; t < XF_THREADS; t++) {
+    for (int t = 0; t < XF_MAX_THREADS; t++) {
         for (int b = 0; b < 2; b++) {
             if (ctx->xf_pin[t][b]) (void)hipHostFree(ctx->xf_pin[t][b]);
             if (ctx->xf_done[t][b]) (void)hipEventDestroy(ctx->xf_done[t][b]);
