@@ -315,13 +315,14 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     uint32_t rk[RX_ITEMS]; // (digit << 16) | rank inside the wave among equal digits; 0xFFFFFFFF = invalid
 
     const uint32_t wbase = (uint32_t)wave * RX_WAVE_TILE + lane;
+    // the positions are not needed before the last staging step: their loads are issued after the ranking (below), so
+    // that the ranking waits for 8 bytes per item instead of 12 and the positions arrive under the look-back
     if (tile_count == RX_TILE) { // full tile: no per-item bounds checks around the loads
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
             const uint64_t g = tile_base + wbase + (uint32_t)j * 64;
             k[j] = key_in[g];
             s[j] = HAS_SEG ? seg_in[g] : 0u;
-            p[j] = pos_in[g];
         }
     } else {
 #pragma unroll
@@ -331,7 +332,6 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
             const uint64_t g = tile_base + li;
             k[j] = valid ? key_in[g] : 0ull;
             s[j] = (HAS_SEG && valid) ? seg_in[g] : 0u;
-            p[j] = valid ? pos_in[g] : 0u;
         }
     }
 #ifdef RX_PROF
@@ -372,6 +372,16 @@ __global__ __launch_bounds__(RX_THREADS, 4) void k_radix_scatter(const uint64_t 
     };
     if (tile_count == RX_TILE) rank_items(std::true_type{});
     else rank_items(std::false_type{});
+    if (tile_count == RX_TILE) {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) p[j] = pos_in[tile_base + wbase + (uint32_t)j * 64];
+    } else {
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const uint32_t li = wbase + (uint32_t)j * 64;
+            p[j] = li < tile_count ? pos_in[tile_base + li] : 0u;
+        }
+    }
     RX_MARK(2);
     __syncthreads();
     RX_MARK(3);
