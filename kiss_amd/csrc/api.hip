@@ -87,6 +87,8 @@ int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
 }
 
 bool kiss_host_is_pinned(const void *p); // xfer.hip
+void *kiss_prefault_start(void *p, uint64_t bytes);
+void kiss_prefault_join(void *handle);
 
 namespace {
 
@@ -565,6 +567,8 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
     ctx->early_used = 0;
     ctx->early_bytes = 0;
     ctx->early_host_SA = early ? SA : nullptr;
+    // a pageable destination: its page faults are taken by helper threads while the device sorts
+    void *prefault = kiss_host_is_pinned(SA) ? nullptr : kiss_prefault_start(SA, (n + 1) * sizeof(uint32_t));
     int rc = sort_dev(ctx, ctx->io_S, n, k, algo, ctx->io_SA, nullptr);
     ctx->early_host_SA = nullptr;
     const auto t2 = clk::now();
@@ -575,9 +579,15 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
             rc = KISS_HIP_E_HIP;
         }
     }
-    if (rc) return rc;
+    if (rc) {
+        kiss_prefault_join(prefault);
+        return rc;
+    }
     if (ctx->early_bytes != (n + 1) * sizeof(uint32_t)) // not armed, or (cannot happen) a stretch was not announced
-        KTRY(kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t)));
+        rc = kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t));
+    // (the helpers are not waited for before the download: what they have not reached yet the copy faults in itself)
+    kiss_prefault_join(prefault);
+    if (rc) return rc;
     const auto t3 = clk::now();
     ctx->stats.ms_h2d = std::chrono::duration<float, std::milli>(t1 - t0).count();
     ctx->stats.ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
