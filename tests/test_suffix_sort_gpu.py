@@ -505,3 +505,22 @@ def test_host_entry_with_page_locked_buffers_downloads_early(oracle, monkeypatch
         SA_pin.fill_(-1)
         c.suffix_sort_host(S_pin.numpy(), SA_pin.numpy().view(np.uint32), k=0xFFFFFFFF, algo=kiss_amd.ALGO_PREFIX_DOUBLING)
         assert np.array_equal(SA_pin.numpy().view(np.uint32), oracle.suffix_sort(S, 0xFFFFFFFF))
+
+
+def test_host_entry_into_a_destination_that_was_never_touched(monkeypatch):
+    # a pageable destination whose pages do not exist yet (numpy.empty of >= 64 MB): helper threads populate them while
+    # the device sorts (xfer.hip: kiss_prefault_start); same suffix array as into a touched buffer and as with the
+    # helpers switched off
+    import kiss_amd
+    S = gen.iid(20_000_000, 77)
+    with kiss_amd.Context(max_n=S.size, device=0) as c:
+        warm = np.zeros(S.size + 1, dtype=np.uint32)
+        c.suffix_sort_host(S, warm, k=256)
+        assert warm[0] == S.size
+        fresh = np.empty(S.size + 1, dtype=np.uint32)   # 80 MB straight from mmap: not one page present
+        c.suffix_sort_host(S, fresh, k=256)
+        assert np.array_equal(fresh, warm)
+        monkeypatch.setenv("KISS_HIP_PREFAULT_THREADS", "1")
+        fresh2 = np.empty(S.size + 1, dtype=np.uint32)
+        c.suffix_sort_host(S, fresh2, k=256)
+        assert np.array_equal(fresh2, warm)
