@@ -54,26 +54,43 @@ RECIPES = [
     ["endrepeat", 200_000, 34, 256], ["endrepeat", 200_000, 35, 257], ["endrepeat", 200_000, 36, 374],
     ["endrepeat", 200_000, 37, 375], ["endrepeat", 200_000, 38, 376], ["endrepeat", 200_000, 39, 1000],
     ["iid", 1, 1], ["iid", 2, 2], ["iid", 5, 3], ["iid", 16, 4], ["iid", 50, 5], ["iid", 1000, 6], ["iid", 100_003, 7],
-]
+    # round 2: shapes behind the code paths that changed (no merged LMS copy: the near-end rank table; round 0 in one pass;
+    # the tied-segment arrays regrown after the first attempt)
+    ["periodic", 300_000, 2, 27, 0],            # (AC)^n: every LMS suffix tied after round 0
+    ["periodic", 600_000, 2052, 26, 6000],      # higher-order-repeat-like array: a 2052-base unit at 1 % divergence
+    ["genome_like", 3_000_000, 31],
+    ["iid", 60_000, 51], ["iid", 30_000, 52], ["genome_like", 400_000, 53],   # k so large that a third of the LMS
+]                                                                               # suffixes are near-end (KS below)
+# orders other than the default (32, 256, exact) for a recipe
+KS = {("iid", 60_000, 51): (20_000,), ("iid", 30_000, 52): (10_000, 29_000), ("genome_like", 400_000, 53): (100_000,)}
 
 if __name__ == "__main__":
     orc, ref = oracle_binding.load(), ref_binding.load()
     T = min(8, ref.max_threads())
     pins = []
+    T_all = T
     for recipe in RECIPES:
         S = make_input(recipe)
+        T = T_all
         lms_asc, _ = ref.get_lms(S, T)
+        if not np.array_equal(lms_asc, orc.get_lms(S)[0]):
+            # seen on (TC)^n, n = 300 000: at the maximal LMS density (every other position) the reference's get_lms
+            # returns a list with three entries out of place when it runs on 8 threads, and the right one on 1 or 2 --
+            # its output depends on the thread count there.  Such a recipe is pinned with the single-thread run.
+            T = 1
+            lms_asc, _ = ref.get_lms(S, T)
+            print("NOTE: reference get_lms is thread-count dependent on", recipe, "-- pinned at 1 thread", flush=True)
         assert np.array_equal(lms_asc, orc.get_lms(S)[0]), recipe
-        ks = (256,) if S.size > 5_000_000 else (32, 256, 0xFFFFFFFF)
+        ks = KS.get(tuple(recipe), (256,) if S.size > 5_000_000 else (32, 256, 0xFFFFFFFF))
         for k in ks:
             sa_o, lms_o = orc.suffix_sort(S, k, stages=True)
             sa_r, lms_r = ref.suffix_sort(S, k, T=T, stages=True)                # restated LMS sort + reference induction
             sa_r2 = ref.suffix_sort(S, k, T=T, sorted_lms=lms_o)                  # reference code only, oracle's LMS order
             assert np.array_equal(lms_o, lms_r) and np.array_equal(sa_o, sa_r) and np.array_equal(sa_o, sa_r2), (recipe, k)
-            pins.append({"recipe": recipe, "n": int(S.size), "k": int(k), "m": int(lms_r.size),
+            pins.append({"recipe": recipe, "n": int(S.size), "k": int(k), "m": int(lms_r.size), "ref_threads": int(T),
                          "lms_asc_fnv": "%016x" % orc.fnv(lms_asc), "lms_sorted_fnv": "%016x" % orc.fnv(lms_r),
                          "sa_fnv": "%016x" % orc.fnv(sa_r)})
             print(recipe, k, pins[-1]["sa_fnv"], flush=True)
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_pins.json"), "w") as f:
-        json.dump({"made_by": "tests/golden/make_ref_golden.py", "threads": T, "pins": pins}, f, indent=1)
+        json.dump({"made_by": "tests/golden/make_ref_golden.py", "threads": T_all, "pins": pins}, f, indent=1)
     print("wrote", len(pins), "pins")
