@@ -52,8 +52,10 @@ typedef enum kiss_hip_status {
                                             depends on its thread count, only the k-order property is defined */
 
 /* the reference's size_type is uint32_t and EMPTY = 0xFFFFFFFF, so n + 19 < 2^32
- * (algo/sort/structs.hpp:94, constant.hpp:19-20) */
-#define KISS_HIP_MAX_N 4294967276ull
+ * (algo/sort/structs.hpp:94, constant.hpp:19-20).  Here 4096 less: several kernels run one thread per suffix-array
+ * entry, a HIP grid holds fewer than 2^32 threads per dimension, and n + 1 rounded up to a workgroup has to stay
+ * below that (found by tools/stress_verify.py at n = 2^32 - 20: "invalid configuration argument") */
+#define KISS_HIP_MAX_N 4294963200ull
 
 typedef struct kiss_hip_ctx kiss_hip_ctx;
 

@@ -15,7 +15,7 @@ KISS_HIP_E_INVALID, KISS_HIP_E_NO_DEVICE, KISS_HIP_E_HIP, KISS_HIP_E_NOMEM = -1,
 KISS_HIP_E_UNSUPPORTED, KISS_HIP_E_INTERNAL, KISS_HIP_E_IO, KISS_HIP_E_DEEP = -5, -6, -7, -8
 ALGO_PARALLEL_SORTING = 0
 ALGO_PREFIX_DOUBLING = 1
-MAX_N = 4294967276
+MAX_N = 4294963200
 
 KERNEL_CLASSES = [
     "pack", "classify", "radix_hist", "radix_scatter", "scan", "keygather", "flag_compact",
