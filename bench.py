@@ -425,6 +425,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_500_000_000,
                     help="bases of the CPU baseline sample (0 = skip); 1.5e9 bases = ~15 s of oracle/_ref time at 24 threads")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
+    ap.add_argument("--sharded-timings", action="store_true",
+                    help="sharded mode: wall-clock ms per phase of rank 0 (adds a synchronisation per phase: a diagnostic, "
+                         "the headline of such a run is slower than a plain one)")
     ap.add_argument("--profile-all", action="store_true",
                     help="time EVERY kernel class inside the timed region (two HIP events per launch, ~560 launches per "
                          "sort: +3 ms per step); default: only the dominant class there, the others in --profile-steps "
@@ -519,8 +522,10 @@ def main():
         from kiss_amd import multi_gpu
         backend = multi_gpu.GpuBackend(ctx, S, k)
 
+        phase_ms = {} if args.sharded_timings else None
+
         def step():
-            multi_gpu.sharded_suffix_sort(backend, n, SA=SA if rank == 0 else None)
+            multi_gpu.sharded_suffix_sort(backend, n, SA=SA if rank == 0 else None, timings=phase_ms)
     else:
         def step():
             ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo, stream=stream)
@@ -530,6 +535,8 @@ def main():
     sharded_error = args.sharded_error  # only ever set by the self-launching parent on its fresh replicas run
     for _ in range(args.warmup):
         step()
+    if sharded and args.sharded_timings:
+        phase_ms.clear()  # the warm-up call holds the first-use allocations and the communicator set-up
 
     def barrier():
         if dist is not None:
@@ -611,6 +618,8 @@ def main():
         }
         if sharded_error:
             out["config"]["sharded_error"] = sharded_error
+        if sharded and args.sharded_timings:
+            out["config"]["sharded_phase_ms_rank0"] = {k: v / args.steps for k, v in phase_ms.items()}
         # roofline of the dominant kernel class (live HIP-event timing inside the library)
         roof = None
         if agg and not args.no_profile:

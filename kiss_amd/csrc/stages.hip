@@ -29,6 +29,21 @@ __global__ __launch_bounds__(ST_THREADS) void k_key_hist(const uint64_t *__restr
     atomicAdd(&hist[keys[i] >> shift], 1ull);
 }
 
+// the same with one private histogram per workgroup in LDS (bits <= 14: 64 KiB of 32-bit counters), flushed once: one
+// global atomic per key on 2^16 bins took 49 ms for the 906 M keys of a chm13-size text (bench.py --sharded-timings)
+__global__ __launch_bounds__(ST_THREADS) void k_key_hist_lds(const uint64_t *__restrict__ keys, uint64_t count, int shift,
+                                                            uint32_t bins, unsigned long long *__restrict__ hist)
+{
+    extern __shared__ uint32_t lh[];
+    for (uint32_t b = threadIdx.x; b < bins; b += ST_THREADS) lh[b] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * ST_THREADS + threadIdx.x; i < count; i += (uint64_t)gridDim.x * ST_THREADS)
+        atomicAdd(&lh[keys[i] >> shift], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += ST_THREADS)
+        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
 __global__ __launch_bounds__(ST_THREADS) void k_group_ids(const uint64_t *__restrict__ keys, uint64_t count, int shift,
                                                          Splitters sp, uint32_t *__restrict__ group)
 {
@@ -92,7 +107,13 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
     KTRY(kiss_zero_u32(ctx, d_hist, 2ull << bits));
-    if (count) {
+    if (count && bits <= 14) {
+        const uint64_t blocks = div_up(count, (uint64_t)ST_THREADS * 64);
+        hipLaunchKernelGGL(k_key_hist_lds, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(ST_THREADS),
+                           (size_t)sizeof(uint32_t) << bits, ctx->stream, d_keys, count, 64 - bits, 1u << bits,
+                           (unsigned long long *)d_hist);
+        KCHECK(hipGetLastError());
+    } else if (count) {
         hipLaunchKernelGGL(k_key_hist, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
                            count, 64 - bits, (unsigned long long *)d_hist);
         KCHECK(hipGetLastError());

@@ -20,7 +20,7 @@ import numpy as np
 from . import _lib
 from .sorter import _check
 
-HIST_BITS = 16
+HIST_BITS = 14   # 7 bases: the histogram is private to a workgroup in LDS (64 KiB), 16 384 bins split <= 64 key ranges finely enough
 EXACT_H0 = 256  # bounded order of the first phase when exact order falls back to rank doubling
 
 
@@ -293,7 +293,21 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     torch = comm.torch
     G, r = comm.world, comm.rank
     lo, hi = (n * r) // G, (n * (r + 1)) // G
+    # timings (a dict, optional): wall-clock ms per phase of THIS rank, each closed by a device synchronisation -- a
+    # diagnostic (bench.py --sharded-timings), not for timed runs: the extra synchronisations serialise what may overlap
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def phase(name):
+        if timings is None:
+            return
+        if hasattr(backend, "_sync"):
+            backend._sync()
+        now = _time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + 1e3 * (now - _t[0])
+        _t[0] = now
     counts = backend.classify(lo, hi)
+    phase("classify")
     keys, pos, m_far = backend.local_lms()
     m_local = int(pos.numel())
     # global counters (sum of the windowed ones)
@@ -303,6 +317,7 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     # near-end suffixes (only the rank(s) owning the end of the text have any) go to rank 0 as they are
     near_counts = comm.all_gather_ints(m_local - m_far)
     near_all = comm.gather_to_root(pos[m_far:], near_counts, backend.empty)
+    phase("counters + near-end gather")
     keys, pos = keys[:m_far], pos[:m_far]
     # key ranges balanced by LMS count
     hist = backend.key_hist(keys, HIST_BITS)
@@ -310,7 +325,9 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     comm.all_reduce(hist)
     splitters = choose_splitters(hist.cpu().numpy(), G)
     send_counts = group_counts(local_hist, splitters, G)
+    phase("key histogram + splitters")
     skeys, spos = backend.partition(keys, pos, HIST_BITS, splitters, G)
+    phase("partition")
     # the exchange: all-to-all of (key, position), receiver keeps source-rank order
     recv_counts, largest = comm.all_to_all_counts(send_counts)
     R = int(sum(recv_counts))
@@ -318,7 +335,9 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     rpos = backend.empty(R, torch.int32)
     comm.all_to_all(rkeys, skeys, recv_counts, send_counts, largest)
     comm.all_to_all(rpos, spos, recv_counts, send_counts, largest)
+    phase("exchange")
     res = backend.sort(rkeys, rpos)
+    phase("sort")
     if int(backend.k) >= n:
         # exact order: a rank whose key range holds ties deeper than the bounded-round path handles (tandem arrays of
         # tens of kilobases) reports it; then every rank runs the pipeline again for k = 256 and rank 0 finishes with
@@ -345,8 +364,10 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     # the context words travel with the pieces (4 more bytes per LMS suffix over xGMI instead of a random text
     # gather per LMS suffix on rank 0)
     ctx_all = comm.gather_to_root(piece_ctx, piece_counts, backend.empty)
+    phase("gather")
     out = None
     if r == 0:
         out = backend.induce(far_all, near_all, counts12, SA, far_ctx=ctx_all)
+    phase("induce")
     comm.barrier()
     return out
