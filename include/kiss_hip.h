@@ -120,6 +120,9 @@ int kiss_hip_device_count(int *count);
 
 /* ---- context: device workspace sized for texts up to max_n bases ------------- */
 int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n);
+/* the same with the capacity of the per-LMS-suffix work arrays chosen by the caller instead of 0.32 max_n: a rank of a
+ * sharded sort (ranks > 0 hold about 1/G of the LMS suffixes; the arrays regrow on demand).  0 = the default. */
+int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, uint64_t lms_capacity);
 int kiss_hip_ctx_destroy(kiss_hip_ctx *ctx);
 /* enable/disable per-kernel HIP-event timing (adds event overhead; off by default) */
 int kiss_hip_ctx_set_profiling(kiss_hip_ctx *ctx, int enabled);
@@ -131,6 +134,9 @@ int kiss_hip_last_hip_error(const kiss_hip_ctx *ctx, const char **msg);
 int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out);
 /* bytes of device workspace the ctx holds */
 int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes);
+/* the host-pointer entry points keep device-side copies of the caller's buffers between calls (5 bytes per base of
+ * max_n, counted in workspace_bytes); this releases them (the next such call allocates them again) */
+int kiss_hip_ctx_release_io_buffers(kiss_hip_ctx *ctx);
 
 /* ---- suffix sorting --------------------------------------------------------- */
 /*
@@ -157,6 +163,38 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
  * returns after the work on `stream` has completed. */
 int kiss_hip_ctx_suffix_sort_dna_u32_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo,
                                          uint32_t *d_SA, void *stream);
+
+/* ---- several GPUs of one node driven by ONE process (`kiss_hip_opts{ngpus, device ids}`) ----
+ * What a `suffix_sort_main`-shaped caller (reference include/command/suffix_sort.hpp:37-61) binds to use more than one
+ * device: same arguments as kiss_hip_suffix_sort_dna_u32 plus the device list.  The LMS sort is sharded by key range
+ * over the devices: devices[0] packs the text and the others pull it, every device classifies
+ * a slice of the text, the LMS list is exchanged by direct peer copies over xGMI (every pair of devices its own link,
+ * receiver keeps source order = text order), every device sorts its key range, devices[0] pulls the sorted pieces and
+ * runs the induction (one dependency chain: it does not shard).  Host threads inside the call, one per device; no
+ * fork, no exec.  A device may be listed more than once (two shares on one GPU: how the path is tested on a one-GPU
+ * box).  ndev = 1 runs the same staged pipeline on one device and moves nothing. */
+typedef struct kiss_hip_multi kiss_hip_multi;
+typedef struct kiss_hip_multi_stats {
+    uint64_t n, m;          /* text length, LMS suffixes */
+    uint32_t ndev;
+    uint32_t refine_depth;  /* != 0: exact order finished by rank doubling from this order on devices[0] */
+    uint64_t piece[8];      /* far LMS suffixes sorted by each of the first 8 devices */
+    /* wall-clock phases of the last call (barrier to barrier, i.e. the slowest device of each phase) */
+    float ms_total, ms_pack, ms_classify, ms_partition, ms_exchange, ms_sort, ms_gather, ms_induce;
+} kiss_hip_multi_stats;
+int kiss_hip_multi_create(kiss_hip_multi **out, const int *devices, int ndev, uint64_t max_n);
+int kiss_hip_multi_destroy(kiss_hip_multi *mc);
+/* host S -> host SA (the reference's timed region); the SA is downloaded from devices[0] */
+int kiss_hip_multi_suffix_sort_dna_u32(kiss_hip_multi *mc, const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA);
+/* d_S (n bytes) and d_SA (n + 1 u32) are device pointers on devices[0] */
+int kiss_hip_multi_suffix_sort_dna_u32_dev(kiss_hip_multi *mc, const uint8_t *d_S, uint64_t n, uint32_t k, int algo,
+                                           uint32_t *d_SA);
+int kiss_hip_multi_get_stats(const kiss_hip_multi *mc, kiss_hip_multi_stats *out);
+/* the per-device context of share `rank` (statistics, profiling switches); owned by mc */
+kiss_hip_ctx *kiss_hip_multi_ctx(kiss_hip_multi *mc, int rank);
+/* one-shot: create, upload, sort, download, free */
+int kiss_hip_suffix_sort_dna_u32_multi(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, const int *devices,
+                                       int ndev);
 
 /* ---- verification (device side; independent of the sort kernels: reads only the caller's text and SA) --------
  * Checks that d_SA (n+1 entries) is what the reference's own tests require of a k-ordered suffix array
@@ -215,6 +253,25 @@ int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, u
                             uint64_t counts13[13], void *stream);
 int kiss_hip_stage_local_lms(kiss_hip_ctx *ctx, uint64_t *d_keys_out /* may be NULL: sizes only */,
                              uint32_t *d_pos_out, uint64_t *m_local, uint64_t *m_far_local);
+/* Zero-copy hand-over between the stages: device pointers of the ctx's own work arrays (capacity = entries each holds).
+ * A caller that passes these very pointers to the stage calls gets no copy in and no copy out:
+ *   LOCAL_KEYS / LOCAL_POS  : what stage_classify emitted (u64 / u32), input of stage_partition, destination of the
+ *                             exchange (the receiver's list) and input of stage_sort
+ *   PART_KEYS / PART_POS    : output of stage_partition = source of the exchange
+ *   SORTED / SORTED_CTX     : output of stage_sort (u32 / u32) = source of the gather; on the rank that runs the
+ *                             induction also its destination and the input of stage_induce
+ * kiss_hip_stage_reserve: makes the arrays hold lms_capacity entries; their CONTENTS ARE LOST when it has to regrow
+ * (call it before stage_classify, or classify again).  The pointers change then: ask for the views afterwards. */
+enum {
+    KISS_HIP_VIEW_LOCAL_KEYS = 0,
+    KISS_HIP_VIEW_LOCAL_POS = 1,
+    KISS_HIP_VIEW_PART_KEYS = 2,
+    KISS_HIP_VIEW_PART_POS = 3,
+    KISS_HIP_VIEW_SORTED = 4,
+    KISS_HIP_VIEW_SORTED_CTX = 5
+};
+int kiss_hip_stage_view(kiss_hip_ctx *ctx, int which, void **d_ptr, uint64_t *capacity);
+int kiss_hip_stage_reserve(kiss_hip_ctx *ctx, uint64_t lms_capacity);
 int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist,
                             void *stream);
 int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
@@ -237,6 +294,10 @@ int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint
  * 32-bit payload, and its exclusive u32 scan, run on caller data in host memory (count <= ctx LMS capacity). */
 int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, uint64_t count, int key_lo_bit);
 int kiss_hip_debug_scan_u32(kiss_hip_ctx *ctx, uint32_t *data, uint64_t count);
+/* host only: the key-range rule of the multi-device sort (kiss_hip_multi_*) on a caller's histogram of `bins` entries:
+ * groups - 1 splitters (group of a bin = number of splitters <= bin) and the resulting items per group */
+int kiss_hip_debug_splitters(const uint64_t *hist, uint64_t bins, int groups, uint32_t *splitters_out,
+                             uint64_t *group_counts_out);
 
 /* ---- FM-index (biovoltron FMIndex<4,uint32_t,...>{LOOKUP_LEN=0}) --------------- */
 /* Raw views of the arrays of the .fmi layout (fm_index.hpp:591-615).

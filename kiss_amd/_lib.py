@@ -16,6 +16,8 @@ KISS_HIP_E_UNSUPPORTED, KISS_HIP_E_INTERNAL, KISS_HIP_E_IO, KISS_HIP_E_DEEP = -5
 ALGO_PARALLEL_SORTING = 0
 ALGO_PREFIX_DOUBLING = 1
 MAX_N = 4294963200
+# kiss_hip_stage_view: the ctx's own work arrays (include/kiss_hip.h)
+VIEW_LOCAL_KEYS, VIEW_LOCAL_POS, VIEW_PART_KEYS, VIEW_PART_POS, VIEW_SORTED, VIEW_SORTED_CTX = range(6)
 
 KERNEL_CLASSES = [
     "pack", "classify", "radix_hist", "radix_scatter", "scan", "keygather", "flag_compact",
@@ -44,6 +46,21 @@ class Stats(ctypes.Structure):
             name: {"ms": self.ms_kernel[i], "launches": self.launches_kernel[i], "items": self.items_kernel[i]}
             for i, name in enumerate(KERNEL_CLASSES)
         }
+        return d
+
+
+class MultiStats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint64), ("m", ctypes.c_uint64), ("ndev", ctypes.c_uint32), ("refine_depth", ctypes.c_uint32),
+        ("piece", ctypes.c_uint64 * 8),
+        ("ms_total", ctypes.c_float), ("ms_pack", ctypes.c_float), ("ms_classify", ctypes.c_float),
+        ("ms_partition", ctypes.c_float), ("ms_exchange", ctypes.c_float), ("ms_sort", ctypes.c_float),
+        ("ms_gather", ctypes.c_float), ("ms_induce", ctypes.c_float),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "piece"}
+        d["piece"] = [int(x) for x in self.piece][:max(1, min(8, self.ndev))]
         return d
 
 
@@ -95,6 +112,21 @@ def load():
     lib.kiss_hip_strerror.argtypes = [ctypes.c_int]
     lib.kiss_hip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
     lib.kiss_hip_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_uint64]
+    lib.kiss_hip_ctx_create_sized.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]
+    lib.kiss_hip_ctx_release_io_buffers.argtypes = [vp]
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.kiss_hip_multi_create.argtypes = [ctypes.POINTER(vp), ip, ctypes.c_int, ctypes.c_uint64]
+    lib.kiss_hip_multi_destroy.argtypes = [vp]
+    lib.kiss_hip_multi_suffix_sort_dna_u32.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp]
+    lib.kiss_hip_multi_suffix_sort_dna_u32_dev.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp]
+    lib.kiss_hip_multi_get_stats.argtypes = [vp, ctypes.POINTER(MultiStats)]
+    lib.kiss_hip_multi_ctx.argtypes = [vp, ctypes.c_int]
+    lib.kiss_hip_multi_ctx.restype = vp
+    lib.kiss_hip_suffix_sort_dna_u32_multi.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, ip, ctypes.c_int]
+    lib.kiss_hip_stage_view.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
+    lib.kiss_hip_stage_reserve.argtypes = [vp, ctypes.c_uint64]
+    lib.kiss_hip_debug_splitters.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, vp, vp]
+    lib.kiss_hip_debug_splitters.restype = ctypes.c_int
     lib.kiss_hip_ctx_destroy.argtypes = [vp]
     lib.kiss_hip_ctx_set_profiling.argtypes = [vp, ctypes.c_int]
     lib.kiss_hip_ctx_set_profiling_mask.argtypes = [vp, ctypes.c_uint64]
@@ -148,7 +180,11 @@ def load():
                  "kiss_hip_ctx_suffix_sort_dna_u32_dev", "kiss_hip_ctx_get_stage_outputs",
                  "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev", "kiss_hip_debug_radix_sort",
                  "kiss_hip_debug_scan_u32", "kiss_hip_stage_classify", "kiss_hip_stage_local_lms",
-                 "kiss_hip_stage_key_hist", "kiss_hip_stage_partition", "kiss_hip_stage_sort", "kiss_hip_stage_induce"):
+                 "kiss_hip_stage_key_hist", "kiss_hip_stage_partition", "kiss_hip_stage_sort", "kiss_hip_stage_induce",
+                 "kiss_hip_ctx_create_sized", "kiss_hip_ctx_release_io_buffers", "kiss_hip_multi_create",
+                 "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32", "kiss_hip_multi_suffix_sort_dna_u32_dev",
+                 "kiss_hip_multi_get_stats", "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_stage_view",
+                 "kiss_hip_stage_reserve"):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib
@@ -171,4 +207,8 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
     "kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file", "kiss_hip_copy_to_host",
     "kiss_hip_free_dev", "kiss_hip_alloc_dev", "kiss_hip_suffix_sort_u8", "kiss_hip_ctx_suffix_sort_u8_dev",
+    "kiss_hip_ctx_create_sized", "kiss_hip_ctx_release_io_buffers", "kiss_hip_stage_view", "kiss_hip_stage_reserve",
+    "kiss_hip_multi_create", "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32",
+    "kiss_hip_multi_suffix_sort_dna_u32_dev", "kiss_hip_multi_get_stats", "kiss_hip_multi_ctx",
+    "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters",
 ]

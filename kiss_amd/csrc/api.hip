@@ -71,7 +71,9 @@ int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0;; spins++) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((spins & 0xFFFF) == 0xFFFF) {
             // a kernel that faulted never publishes: after 5 s ask the runtime what happened instead of spinning on
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -97,9 +99,9 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
 {
     void *q = nullptr;
     uint64_t bytes = (count ? count : 1) * sizeof(T);
-    // fault-injection hook of tests/test_suffix_sort_gpu.py: work arrays above this many bytes "do not fit"
-    const char *cap = getenv("KISS_HIP_FAIL_ALLOC_OVER");
-    hipError_t e = cap && bytes > strtoull(cap, nullptr, 10) ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
+    // fault-injection hook of tests/test_suffix_sort_gpu.py: work arrays above this many bytes "do not fit" (the
+    // environment is looked at once per ctx, kiss_hip_ctx_create_sized; 0 = no limit)
+    hipError_t e = ctx->fail_alloc_over && bytes > ctx->fail_alloc_over ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError(); // (or the next launch check reports this failure as its own)
         ctx->last_hip_error = (int)e;
@@ -273,7 +275,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
 // LMS-sized arrays: DNA has ~0.29-0.30 n LMS suffixes; inputs with more (up to n/2) re-reserve on demand
 static uint64_t default_m_cap(const kiss_hip_ctx *ctx)
 {
-    uint64_t m0 = (uint64_t)(0.32 * (double)ctx->max_n) + 4096;
+    uint64_t m0 = ctx->m_cap0 ? ctx->m_cap0 : (uint64_t)(0.32 * (double)ctx->max_n) + 4096;
     if (m0 > ctx->max_n / 2 + 2) m0 = ctx->max_n / 2 + 2;
     return m0;
 }
@@ -387,6 +389,88 @@ int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
     return rc;
 }
 
+// Host S -> host SA around a device-resident sort on `ctx`'s device (the reference's own timed region,
+// command/suffix_sort.hpp:57-61): upload into the ctx-owned device copies, sort(arg, d_S, d_SA), download -- finished
+// stretches of SA leave while the sweeps still run when SA is page-locked and the order is bounded (xfer.hip).  Shared by
+// the single-device entry and the multi-device one (multi.hip: device 0 runs the induction, so the SA lives there).
+int kiss_host_sort(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, uint32_t *SA,
+                   int (*sort)(void *, const uint8_t *, uint32_t *), void *arg)
+{
+    KCHECK(hipSetDevice(ctx->device));
+    ctx->stream = ctx->own_stream;
+    if (!ctx->io_S || !ctx->io_SA || ctx->io_cap < n) { // device-side copies of the caller's buffers: owned by the ctx, sized for max_n
+        if (ctx->io_S) (void)hipFree(ctx->io_S);
+        if (ctx->io_SA) (void)hipFree(ctx->io_SA);
+        ctx->io_S = nullptr;
+        ctx->io_SA = nullptr;
+        ctx->ws_bytes -= ctx->io_cap ? 5 * ctx->io_cap + 4 : 0;
+        ctx->io_cap = 0;
+        const uint64_t cap = ctx->max_n ? ctx->max_n : 1;
+        hipError_t e = hipMalloc((void **)&ctx->io_S, cap);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->io_SA, (cap + 1) * sizeof(uint32_t));
+        if (e != hipSuccess) { // never half a pair: a later call starts from nothing again
+            (void)hipGetLastError();
+            if (ctx->io_S) (void)hipFree(ctx->io_S);
+            if (ctx->io_SA) (void)hipFree(ctx->io_SA);
+            ctx->io_S = nullptr;
+            ctx->io_SA = nullptr;
+            ctx->last_hip_error = (int)e;
+            return KISS_HIP_E_NOMEM;
+        }
+        ctx->io_cap = cap;
+        ctx->ws_bytes += 5 * cap + 4;
+    }
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    KTRY(kiss_xfer_h2d(ctx, ctx->io_S, S, n));
+    const auto t1 = clk::now();
+    // bounded order into a page-locked buffer: finished stretches of SA leave while the sweeps still run (xfer.hip)
+    const bool no_early = getenv("KISS_HIP_NO_EARLY_OUT") != nullptr; // A-B hook, read per call
+    const bool early = !no_early && n >= (1u << 22) && (uint64_t)k < n && kiss_host_is_pinned(SA);
+    ctx->early_used = 0;
+    ctx->early_bytes = 0;
+    ctx->early_host_SA = early ? SA : nullptr;
+    // a pageable destination: its page faults are taken by helper threads while the device sorts
+    void *prefault = kiss_host_is_pinned(SA) ? nullptr : kiss_prefault_start(SA, (n + 1) * sizeof(uint32_t));
+    int rc = sort(arg, ctx->io_S, ctx->io_SA);
+    ctx->early_host_SA = nullptr;
+    (void)hipSetDevice(ctx->device);
+    const auto t2 = clk::now();
+    if (ctx->early_stream && ctx->early_used) {
+        const hipError_t e = hipStreamSynchronize(ctx->early_stream);
+        if (rc == KISS_HIP_OK && e != hipSuccess) {
+            ctx->last_hip_error = (int)e;
+            rc = KISS_HIP_E_HIP;
+        }
+    }
+    if (rc) {
+        kiss_prefault_join(prefault);
+        return rc;
+    }
+    if (ctx->early_bytes != (n + 1) * sizeof(uint32_t)) // not armed, or (cannot happen) a stretch was not announced
+        rc = kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t));
+    // (the helpers are not waited for before the download: what they have not reached yet the copy faults in itself)
+    kiss_prefault_join(prefault);
+    if (rc) return rc;
+    const auto t3 = clk::now();
+    ctx->stats.ms_h2d = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    ctx->stats.ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
+    return KISS_HIP_OK;
+}
+
+// releases the device-side copies of the caller's buffers the host-pointer entry points keep between calls (5 bytes per
+// base of max_n); the next such call allocates them again
+int kiss_io_release(kiss_hip_ctx *ctx)
+{
+    if (ctx->io_S) (void)hipFree(ctx->io_S);
+    if (ctx->io_SA) (void)hipFree(ctx->io_SA);
+    ctx->io_S = nullptr;
+    ctx->io_SA = nullptr;
+    ctx->ws_bytes -= ctx->io_cap ? 5 * ctx->io_cap + 4 : 0;
+    ctx->io_cap = 0;
+    return KISS_HIP_OK;
+}
+
 extern "C" {
 
 int kiss_hip_version(void) { return KISS_HIP_VERSION; }
@@ -421,6 +505,11 @@ int kiss_hip_device_count(int *count)
 
 int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
 {
+    return kiss_hip_ctx_create_sized(out, device, max_n, 0);
+}
+
+int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, uint64_t lms_capacity)
+{
     if (!out || max_n > KISS_HIP_MAX_N) return KISS_HIP_E_INVALID;
     *out = nullptr;
     int ndev = 0;
@@ -429,6 +518,8 @@ int kiss_hip_ctx_create(kiss_hip_ctx **out, int device, uint64_t max_n)
     if (!ctx) return KISS_HIP_E_NOMEM;
     ctx->device = device;
     ctx->max_n = max_n;
+    ctx->m_cap0 = lms_capacity ? lms_capacity + 4096 : 0;
+    if (const char *cap = getenv("KISS_HIP_FAIL_ALLOC_OVER")) ctx->fail_alloc_over = strtoull(cap, nullptr, 10);
     int rc = KISS_HIP_OK;
     do {
         if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
@@ -520,6 +611,13 @@ int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out)
     return KISS_HIP_OK;
 }
 
+int kiss_hip_ctx_release_io_buffers(kiss_hip_ctx *ctx)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    return kiss_io_release(ctx);
+}
+
 int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes)
 {
     if (!ctx || !bytes) return KISS_HIP_E_INVALID;
@@ -538,60 +636,18 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
 {
     if (!ctx || !SA || (n && !S)) return KISS_HIP_E_INVALID;
     if (n > ctx->max_n) return KISS_HIP_E_INVALID;
-    KCHECK(hipSetDevice(ctx->device));
-    ctx->stream = ctx->own_stream;
-    if (!ctx->io_S || ctx->io_cap < n) { // device-side copies of the caller's buffers: owned by the ctx, sized for max_n
-        if (ctx->io_S) (void)hipFree(ctx->io_S);
-        if (ctx->io_SA) (void)hipFree(ctx->io_SA);
-        ctx->io_S = nullptr;
-        ctx->io_SA = nullptr;
-        ctx->ws_bytes -= ctx->io_cap ? 5 * ctx->io_cap + 4 : 0;
-        ctx->io_cap = 0;
-        const uint64_t cap = ctx->max_n ? ctx->max_n : 1;
-        hipError_t e = hipMalloc((void **)&ctx->io_S, cap);
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->io_SA, (cap + 1) * sizeof(uint32_t));
-        if (e != hipSuccess) {
-            ctx->last_hip_error = (int)e;
-            return KISS_HIP_E_NOMEM;
-        }
-        ctx->io_cap = cap;
-        ctx->ws_bytes += 5 * cap + 4;
-    }
-    using clk = std::chrono::steady_clock;
-    const auto t0 = clk::now();
-    KTRY(kiss_xfer_h2d(ctx, ctx->io_S, S, n));
-    const auto t1 = clk::now();
-    // bounded order into a page-locked buffer: finished stretches of SA leave while the sweeps still run (xfer.hip)
-    static const bool no_early = getenv("KISS_HIP_NO_EARLY_OUT") != nullptr; // A-B hook
-    const bool early = !no_early && n >= (1u << 22) && (uint64_t)k < n && kiss_host_is_pinned(SA);
-    ctx->early_used = 0;
-    ctx->early_bytes = 0;
-    ctx->early_host_SA = early ? SA : nullptr;
-    // a pageable destination: its page faults are taken by helper threads while the device sorts
-    void *prefault = kiss_host_is_pinned(SA) ? nullptr : kiss_prefault_start(SA, (n + 1) * sizeof(uint32_t));
-    int rc = sort_dev(ctx, ctx->io_S, n, k, algo, ctx->io_SA, nullptr);
-    ctx->early_host_SA = nullptr;
-    const auto t2 = clk::now();
-    if (ctx->early_stream && ctx->early_used) {
-        const hipError_t e = hipStreamSynchronize(ctx->early_stream);
-        if (rc == KISS_HIP_OK && e != hipSuccess) {
-            ctx->last_hip_error = (int)e;
-            rc = KISS_HIP_E_HIP;
-        }
-    }
-    if (rc) {
-        kiss_prefault_join(prefault);
-        return rc;
-    }
-    if (ctx->early_bytes != (n + 1) * sizeof(uint32_t)) // not armed, or (cannot happen) a stretch was not announced
-        rc = kiss_xfer_d2h(ctx, SA, ctx->io_SA, (n + 1) * sizeof(uint32_t));
-    // (the helpers are not waited for before the download: what they have not reached yet the copy faults in itself)
-    kiss_prefault_join(prefault);
-    if (rc) return rc;
-    const auto t3 = clk::now();
-    ctx->stats.ms_h2d = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    ctx->stats.ms_d2h = std::chrono::duration<float, std::milli>(t3 - t2).count();
-    return KISS_HIP_OK;
+    struct Arg {
+        kiss_hip_ctx *ctx;
+        uint64_t n;
+        uint32_t k;
+        int algo;
+    } a{ctx, n, k, algo};
+    return kiss_host_sort(ctx, S, n, k, SA,
+                          [](void *p, const uint8_t *d_S, uint32_t *d_SA) {
+                              Arg *q = static_cast<Arg *>(p);
+                              return sort_dev(q->ctx, d_S, q->n, q->k, q->algo, d_SA, nullptr);
+                          },
+                          &a);
 }
 
 int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device)

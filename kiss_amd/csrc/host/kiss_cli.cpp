@@ -7,7 +7,8 @@
 //   fmindex_query  [-q STR] [-n NUM(=10)] [-b patterns.bin]                                  (command/fmindex_query.hpp)
 // and its log fields ("n = …, k = …, suffix sorting elapsed …", "query = … found N times", "searching time",
 // "number of matched locations", "location checksum").  Extras (opt-in): --output-sa FILE (raw u32 LE, n+1
-// entries; the reference never writes the SA), --device N.
+// entries; the reference never writes the SA), --device N, and for suffix_sort --gpus N / --devices LIST (the LMS sort
+// sharded over several GPUs of the node by ONE process, kiss_hip_multi_*; include/kiss_hip.h).
 // Input handling as utils/io.hpp:6-18 + suffix_sort.hpp:33: FASTA if the first byte is '>' (all records
 // concatenated), else plain text lines; ACGT/acgt -> 0..3, every other character -> 4 % 4 = 0 (A).
 #include <algorithm>
@@ -42,7 +43,9 @@ void usage()
               << "./kiss suffix_sort [--option ...] <FASTA filename/Text filename>\n"
               << "  -k [ --kordered ] NUM (=256)   k-ordered value; -1 indicates unbounded sorting\n"
               << "  -s [ --sorting-algorithm ] ALGO (=PARALLEL_SORTING)   PARALLEL_SORTING or PREFIX_DOUBLING\n"
-              << "  --output-sa FILE               also write the suffix array (raw uint32 LE, n+1 entries)\n\n"
+              << "  --output-sa FILE               also write the suffix array (raw uint32 LE, n+1 entries)\n"
+              << "  --gpus NUM (=1)                shard the LMS sort over NUM devices (--device, --device + 1, ...)\n"
+              << "  --devices LIST                 the same with an explicit comma-separated device list\n\n"
               << "./kiss fmindex_build [--option ...] <FASTA filename/Text filename>\n"
               << "  -k [ --kordered ] NUM (=256)   accepted and ignored (the index is built with k = 32)\n\n"
               << "./kiss fmindex_query [--option ...] <FASTA filename/Text filename>\n"
@@ -95,10 +98,16 @@ struct DeviceText {
         check(kiss_hip_copy_to_host(S.data(), d_S, n), "kiss_hip_copy_to_host");
         return S;
     }
+    // the multi-device path brings its own per-device contexts: give this one's workspace back, keep the text
+    void release_ctx()
+    {
+        if (ctx) kiss_hip_ctx_destroy(ctx);
+        ctx = nullptr;
+    }
     ~DeviceText()
     {
         kiss_hip_free_dev(d_S);
-        kiss_hip_ctx_destroy(ctx);
+        if (ctx) kiss_hip_ctx_destroy(ctx);
     }
     DeviceText(const DeviceText &) = delete;
     DeviceText &operator=(const DeviceText &) = delete;
@@ -108,7 +117,8 @@ struct Args {
     std::string command, fasta, query, batch, output_sa, algo = "PARALLEL_SORTING";
     long long k = 256;
     size_t headn = 10;
-    int device = 0;
+    int device = 0, gpus = 1;
+    std::vector<int> devices; // --devices; empty: device, device + 1, ... (gpus of them)
     bool verbose = false, generic = false;
 };
 
@@ -134,10 +144,28 @@ Args parse(int argc, char **argv)
         else if (s == "-n" || s == "--headn") a.headn = (size_t)std::stoull(next("--headn"));
         else if (s == "-b" || s == "--batch") a.batch = next("--batch");
         else if (s == "--output-sa") a.output_sa = next("--output-sa");
+        else if (s == "--gpus") a.gpus = std::stoi(next("--gpus"));
+        else if (s == "--devices") {
+            const std::string list = next("--devices");
+            size_t at = 0;
+            while (at <= list.size()) {
+                const size_t comma = list.find(',', at);
+                const std::string item = list.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+                if (item.empty()) throw std::runtime_error("--devices: empty entry in '" + list + "'");
+                a.devices.push_back(std::stoi(item));
+                if (comma == std::string::npos) break;
+                at = comma + 1;
+            }
+        }
         else if (!s.empty() && s[0] == '-' && s.size() > 1) throw std::runtime_error("unrecognised option '" + s + "'");
         else pos.push_back(s);
     }
     if (pos.empty()) { usage(); std::exit(1); }
+    if (a.gpus < 1) throw std::runtime_error("--gpus must be >= 1");
+    if (a.devices.empty())
+        for (int g = 0; g < a.gpus; g++) a.devices.push_back(a.device + g);
+    else
+        a.device = a.devices[0]; // the text is loaded, and the induction runs, on the first device of the list
     a.command = pos[0];
     if (pos.size() < 2) throw std::runtime_error("the option '--fasta' is required but missing");
     a.fasta = pos[1];
@@ -248,13 +276,35 @@ int suffix_sort_main(const Args &a)
     const auto ta = std::chrono::steady_clock::now();
     check(kiss_hip_alloc_dev(&d_SA, (T.n + 1) * sizeof(uint32_t)), "kiss_hip_alloc_dev");
     const double alloc_s = seconds_since(ta);
+    const bool multi = a.devices.size() > 1;
+    kiss_hip_multi *mc = nullptr;
+    double multi_create_s = 0;
+    if (multi) { // one process, several devices: per-device contexts of their own (the loader's workspace goes back first)
+        T.release_ctx();
+        const auto tc = std::chrono::steady_clock::now();
+        check(kiss_hip_multi_create(&mc, a.devices.data(), (int)a.devices.size(), T.n ? T.n : 1), "kiss_hip_multi_create");
+        multi_create_s = seconds_since(tc);
+    }
     const auto t0 = std::chrono::steady_clock::now(); // the reference starts its stopwatch here (suffix_sort.hpp:57)
-    check(kiss_hip_ctx_suffix_sort_dna_u32_dev(T.ctx, T.d_S, T.n, k, algo, (uint32_t *)d_SA, nullptr),
-          "kiss_hip_ctx_suffix_sort_dna_u32_dev");
+    if (multi)
+        check(kiss_hip_multi_suffix_sort_dna_u32_dev(mc, T.d_S, T.n, k, algo, (uint32_t *)d_SA),
+              "kiss_hip_multi_suffix_sort_dna_u32_dev");
+    else
+        check(kiss_hip_ctx_suffix_sort_dna_u32_dev(T.ctx, T.d_S, T.n, k, algo, (uint32_t *)d_SA, nullptr),
+              "kiss_hip_ctx_suffix_sort_dna_u32_dev");
     const double el = seconds_since(t0);
     std::fprintf(stderr, "[info] n = %llu, k = %llu, suffix sorting elapsed %.6f\n", (unsigned long long)T.n,
                  (unsigned long long)(a.k < 0 ? ~0ull : (unsigned long long)a.k), el);
-    if (a.verbose) {
+    if (multi && a.verbose) {
+        kiss_hip_multi_stats ms;
+        kiss_hip_multi_get_stats(mc, &ms);
+        std::fprintf(stderr, "[debug] %u devices (workspaces %.6f s): pack + broadcast %.3f ms, get_lms per slice %.3f ms, "
+                             "partition %.3f ms, exchange %.3f ms, lms_suffix_direct_sort per key range %.3f ms, gather %.3f ms, "
+                             "put_lms_suffix + induced_sort %.3f ms, total %.3f ms; lms = %llu\n",
+                     ms.ndev, multi_create_s, ms.ms_pack, ms.ms_classify, ms.ms_partition, ms.ms_exchange, ms.ms_sort,
+                     ms.ms_gather, ms.ms_induce, ms.ms_total, (unsigned long long)ms.m);
+    }
+    if (!multi && a.verbose) {
         kiss_hip_stats st;
         kiss_hip_get_stats(T.ctx, &st);
         std::fprintf(stderr, "[debug] device workspace %.6f s; read + upload + device-side parse of %s %.6f s; SA buffer %.6f s\n",
@@ -277,6 +327,7 @@ int suffix_sort_main(const Args &a)
         }
     }
     const auto tf = std::chrono::steady_clock::now();
+    if (mc) kiss_hip_multi_destroy(mc);
     kiss_hip_free_dev(d_SA);
     if (a.verbose) std::fprintf(stderr, "[debug] SA buffer released in %.6f s\n", seconds_since(tf));
     return 0;

@@ -44,6 +44,8 @@ struct kiss_hip_ctx {
     hipStream_t stream = nullptr;  // stream of the current call
     uint64_t max_n = 0;
     uint64_t m_cap = 0;            // capacity of the per-LMS arrays (every LMS suffix of the text)
+    uint64_t fail_alloc_over = 0;  // test hook (KISS_HIP_FAIL_ALLOC_OVER, read when the ctx is created): see dmalloc
+    uint64_t m_cap0 = 0;           // != 0: the caller's choice of the default reservation (kiss_hip_ctx_create_sized)
     uint64_t t_cap = 0;            // capacity of the tied-segment arrays (suffixes still tied after round 0)
     uint64_t flags_cap = 0;        // u64 entries in `flags`
     uint64_t tied_bytes = 0;
@@ -133,7 +135,7 @@ struct kiss_hip_ctx {
     void *xf_pin[16][2] = {};
     hipEvent_t xf_done[16][2] = {};
     hipStream_t xf_stream[16] = {};
-    bool xf_ready = false;
+    int xf_ready = 0; // copy threads whose streams / bounce buffers exist
 
     // state of the last call (for stage outputs / stats)
     uint64_t n = 0, m = 0, m_far = 0;
@@ -188,6 +190,11 @@ struct RadixBufs {
 };
 int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_bit, int seg_bits, int *result_idx);
 int kiss_radix_check(kiss_hip_ctx *ctx); // synchronises; KISS_HIP_E_INTERNAL if a look-back wait ran out
+// stages.hip: pieces of the sharded form shared with multi.hip (all queued on ctx->stream, not synchronised)
+uint64_t kiss_depth_of(uint64_t n, uint32_t k);
+int kiss_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist);
+int kiss_partition_by_splitters(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
+                                const uint32_t *splitters, int groups, uint64_t *d_keys_out, uint32_t *d_pos_out);
 // k-ordered LMS sort of the far suffixes -> ctx->lms_sorted_far
 int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // kiss_lms_sort in exact mode gives up (no output) once suffixes still tie after this many bases

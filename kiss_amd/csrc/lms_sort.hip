@@ -1734,7 +1734,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffix-array entries are tainted\n", hc, (unsigned long long)total);
             }
             // the context words are still in CTX (it becomes the inverse suffix array only after this kernel)
-            static const bool no_taint = getenv("KISS_HIP_NO_TAINT") != nullptr; // A-B hook: compare every neighbour pair
+            const bool no_taint = getenv("KISS_HIP_NO_TAINT") != nullptr; // A-B hook (read per call): compare every neighbour pair
             bool done = false;
             if (!no_taint && ctx->ctx_words_valid) {
                 // candidates first, compared densely afterwards; the list lives in posA (dead here).  More candidates than

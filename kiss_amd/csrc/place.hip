@@ -280,14 +280,19 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
 
 // far_ctx[j] |= taint for j in [run_start[e], near_idx[e]): NT_BLOCKS workgroups per near suffix, grid-stride over its run
 constexpr uint32_t NT_BLOCKS = 16;
+// (the grid is capped: with E in the millions -- a bounded k of several million bases -- NT_BLOCKS * E workgroups of 256
+//  threads would pass the 2^32 threads a HIP grid dimension holds; the workgroups stride over the (suffix, part) pairs)
+constexpr uint32_t NT_MAX_GRID = 1u << 20;
 __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__restrict__ run_start,
                                                              const uint32_t *__restrict__ near_idx,
-                                                             uint32_t *__restrict__ far_ctx)
+                                                             uint32_t *__restrict__ far_ctx, uint32_t E)
 {
-    const uint32_t e = blockIdx.x / NT_BLOCKS, sub = blockIdx.x % NT_BLOCKS;
-    const uint64_t lo = run_start[e], hi = near_idx[e];
-    for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS)
-        far_ctx[j] |= KISS_CTX_TAINT; // (a word of 0 = "gather me" becomes 0x80000000: still gathered, see k_merge_far)
+    for (uint64_t b = blockIdx.x; b < (uint64_t)NT_BLOCKS * E; b += gridDim.x) {
+        const uint32_t e = (uint32_t)(b / NT_BLOCKS), sub = (uint32_t)(b % NT_BLOCKS);
+        const uint64_t lo = run_start[e], hi = near_idx[e];
+        for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS)
+            far_ctx[j] |= KISS_CTX_TAINT; // (a word of 0 = "gather me" becomes 0x80000000: still gathered, see k_merge_far)
+    }
 }
 
 } // namespace
@@ -365,6 +370,8 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     {
         KTimer t(ctx, KISS_HIP_K_PLACE, m);
         const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
+        const uint64_t tie_blocks = (uint64_t)NT_BLOCKS * E;
+        const unsigned tie_grid = (unsigned)(tie_blocks < NT_MAX_GRID ? (tie_blocks ? tie_blocks : 1) : NT_MAX_GRID);
         if (E > 0 && E >= merge_min) {
             // sort the near-end suffixes among themselves, then rank them against the far list
             const uint32_t *cur = ctx->lms_pos + m_far; // ascending text positions = runs of length 1
@@ -383,8 +390,8 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                                    ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
-                hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far);
+                hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                                   ctx->lms_ctx_far, E);
             }
             ctx->near_form = 2;
             ctx->near_sorted = near_sorted;
@@ -399,8 +406,8 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                                    ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
-                hipLaunchKernelGGL(k_near_tie_mark, dim3(NT_BLOCKS * E), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far);
+                hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
+                                   ctx->lms_ctx_far, E);
             }
             // (stream order: k_near_tie_mark has read near_tmp2 before the table overwrites it)
             hipLaunchKernelGGL(k_near_table, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, near_pos, ctx->near_fin, E, ctx->near_tmp,

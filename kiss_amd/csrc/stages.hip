@@ -55,13 +55,65 @@ __global__ __launch_bounds__(ST_THREADS) void k_group_ids(const uint64_t *__rest
     group[i] = g;
 }
 
-uint64_t depth_of(uint64_t n, uint32_t k)
+} // namespace
+
+uint64_t kiss_depth_of(uint64_t n, uint32_t k)
 {
     if ((uint64_t)k >= n) return 0;
     return (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
 }
+static uint64_t depth_of(uint64_t n, uint32_t k) { return kiss_depth_of(n, k); }
 
-} // namespace
+// histogram (u64[2^bits]) of the first `bits` key bits; queued on ctx->stream, not synchronised
+int kiss_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist)
+{
+    KTRY(kiss_zero_u32(ctx, d_hist, 2ull << bits));
+    if (count && bits <= 14) {
+        const uint64_t blocks = div_up(count, (uint64_t)ST_THREADS * 64);
+        hipLaunchKernelGGL(k_key_hist_lds, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(ST_THREADS),
+                           (size_t)sizeof(uint32_t) << bits, ctx->stream, d_keys, count, 64 - bits, 1u << bits,
+                           (unsigned long long *)d_hist);
+        KCHECK(hipGetLastError());
+    } else if (count) {
+        hipLaunchKernelGGL(k_key_hist, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
+                           count, 64 - bits, (unsigned long long *)d_hist);
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}
+
+// stable partition of (key, pos) by destination group g = #{splitters <= first `bits` key bits}: one radix pass on the
+// group id.  The ids live in lms_sorted_far / lms_ctx_far (m_cap entries each, free until the sort writes its output).
+// Queued on ctx->stream; groups == 1 moves nothing (the caller keeps using the input buffers).
+int kiss_partition_by_splitters(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_t *d_pos, uint64_t count, int bits,
+                                const uint32_t *splitters, int groups, uint64_t *d_keys_out, uint32_t *d_pos_out)
+{
+    if (count == 0 || groups <= 1) return KISS_HIP_OK;
+    if (count > ctx->m_cap) return KINTERNAL();
+    Splitters sp;
+    sp.count = groups - 1;
+    for (int t = 0; t < groups - 1; t++) sp.s[t] = splitters[t];
+    uint32_t *gid0 = ctx->lms_sorted_far, *gid1 = ctx->lms_ctx_far;
+    hipLaunchKernelGGL(k_group_ids, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
+                       count, 64 - bits, sp, gid0);
+    KCHECK(hipGetLastError());
+    if (count == 1) {
+        KCHECK(hipMemcpyAsync(d_keys_out, d_keys, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KCHECK(hipMemcpyAsync(d_pos_out, d_pos, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return KISS_HIP_OK;
+    }
+    RadixBufs rb;
+    rb.key[0] = const_cast<uint64_t *>(d_keys);
+    rb.key[1] = d_keys_out;
+    rb.pos[0] = const_cast<uint32_t *>(d_pos);
+    rb.pos[1] = d_pos_out;
+    rb.seg[0] = gid0;
+    rb.seg[1] = gid1;
+    int res = 0;
+    KTRY(kiss_radix_sort(ctx, rb, count, 64, 8, &res));
+    if (res != 1) return KINTERNAL();
+    return KISS_HIP_OK;
+}
 
 extern "C" {
 
@@ -99,6 +151,36 @@ int kiss_hip_stage_local_lms(kiss_hip_ctx *ctx, uint64_t *d_keys_out, uint32_t *
     return KISS_HIP_OK;
 }
 
+int kiss_hip_stage_view(kiss_hip_ctx *ctx, int which, void **d_ptr, uint64_t *capacity)
+{
+    if (!ctx || !d_ptr) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    KTRY(kiss_workspace_ready(ctx));
+    void *p = nullptr;
+    switch (which) {
+    case KISS_HIP_VIEW_LOCAL_KEYS: p = ctx->keyA; break;
+    case KISS_HIP_VIEW_LOCAL_POS: p = ctx->lms_pos; break;
+    case KISS_HIP_VIEW_PART_KEYS: p = ctx->keyB; break;
+    case KISS_HIP_VIEW_PART_POS: p = ctx->posB; break;
+    case KISS_HIP_VIEW_SORTED: p = ctx->lms_sorted_far; break;
+    case KISS_HIP_VIEW_SORTED_CTX: p = ctx->lms_ctx_far; break;
+    default: return KISS_HIP_E_INVALID;
+    }
+    *d_ptr = p;
+    if (capacity) *capacity = ctx->m_cap;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_reserve(kiss_hip_ctx *ctx, uint64_t lms_capacity)
+{
+    if (!ctx || lms_capacity > ctx->max_n / 2 + 2) return KISS_HIP_E_INVALID;
+    KCHECK(hipSetDevice(ctx->device));
+    KTRY(kiss_workspace_ready(ctx));
+    if (lms_capacity <= ctx->m_cap) return KISS_HIP_OK;
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    return kiss_lms_reserve(ctx, lms_capacity + lms_capacity / 64 + 1024);
+}
+
 int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t count, int bits, uint64_t *d_hist,
                             void *stream)
 {
@@ -106,18 +188,7 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
     KCHECK(hipSetDevice(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
-    KTRY(kiss_zero_u32(ctx, d_hist, 2ull << bits));
-    if (count && bits <= 14) {
-        const uint64_t blocks = div_up(count, (uint64_t)ST_THREADS * 64);
-        hipLaunchKernelGGL(k_key_hist_lds, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(ST_THREADS),
-                           (size_t)sizeof(uint32_t) << bits, ctx->stream, d_keys, count, 64 - bits, 1u << bits,
-                           (unsigned long long *)d_hist);
-        KCHECK(hipGetLastError());
-    } else if (count) {
-        hipLaunchKernelGGL(k_key_hist, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
-                           count, 64 - bits, (unsigned long long *)d_hist);
-        KCHECK(hipGetLastError());
-    }
+    KTRY(kiss_key_hist(ctx, d_keys, count, bits, d_hist));
     KCHECK(hipStreamSynchronize(ctx->stream));
     return KISS_HIP_OK;
 }
@@ -133,28 +204,12 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
     if (count == 0) return KISS_HIP_OK;
-    if (count > ctx->t_cap) KTRY(kiss_tied_reserve(ctx, count + count / 64 + 1024)); // group ids use the segment arrays
-    Splitters sp;
-    sp.count = groups - 1;
-    for (int t = 0; t < groups - 1; t++) sp.s[t] = splitters[t];
-    hipLaunchKernelGGL(k_group_ids, dim3((unsigned)div_up(count, ST_THREADS)), dim3(ST_THREADS), 0, ctx->stream, d_keys,
-                       count, 64 - bits, sp, ctx->segA);
-    KCHECK(hipGetLastError());
-    if (count == 1 || groups == 1) { // nothing to move
-        KCHECK(hipMemcpyAsync(d_keys_out, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        KCHECK(hipMemcpyAsync(d_pos_out, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (groups == 1) { // nothing to move (callers that hold views of the ctx's own buffers skip this call altogether)
+        if (d_keys_out != d_keys) KCHECK(hipMemcpyAsync(d_keys_out, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_pos_out != d_pos) KCHECK(hipMemcpyAsync(d_pos_out, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
-        // one stable radix pass on the group id (the library's sort, digit source = the id array)
-        RadixBufs rb;
-        rb.key[0] = const_cast<uint64_t *>(d_keys);
-        rb.key[1] = d_keys_out;
-        rb.pos[0] = const_cast<uint32_t *>(d_pos);
-        rb.pos[1] = d_pos_out;
-        rb.seg[0] = ctx->segA;
-        rb.seg[1] = ctx->segB;
-        int res = 0;
-        KTRY(kiss_radix_sort(ctx, rb, count, 64, 8, &res));
-        if (res != 1) return KINTERNAL();
+        if (d_keys_out == d_keys || d_pos_out == d_pos) return KISS_HIP_E_INVALID;
+        KTRY(kiss_partition_by_splitters(ctx, d_keys, d_pos, count, bits, splitters, groups, d_keys_out, d_pos_out));
     }
     return kiss_radix_check(ctx);
 }
@@ -168,12 +223,15 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
     if (count > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, count + count / 64 + 1024));
-    if (count) {
+    // the ctx's own buffers (kiss_hip_stage_view) are sorted where they are: no copy in, no copy out
+    const bool in_place = count && d_keys == ctx->keyA && d_pos == ctx->lms_pos;
+    if (count && !in_place) {
         KCHECK(hipMemcpyAsync(ctx->keyA, d_keys, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KCHECK(hipMemcpyAsync(ctx->lms_pos, d_pos, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    // the digit counts of the emit pass stay good only for the very list it emitted (one rank, nothing exchanged)
+    if (!(in_place && ctx->rx_ghist_count == count && count == ctx->m_far)) ctx->rx_ghist_count = 0;
     ctx->m = ctx->m_far = count;
-    ctx->rx_ghist_count = 0; // these keys did not come from this context's emit pass
     {
         const int rc = kiss_lms_sort(ctx, n, k, depth_of(n, k));
         if (rc == KISS_INTERNAL_TOO_DEEP) { // exact order on very long repeats: the caller switches to k = 256 + doubling
@@ -183,8 +241,9 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
         if (rc) return rc;
     }
     if (count) {
-        KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        if (d_ctx_out) // context words from the key payload (0 = to be gathered), parallel to the sorted positions
+        if (d_sorted_out != ctx->lms_sorted_far)
+            KCHECK(hipMemcpyAsync(d_sorted_out, ctx->lms_sorted_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_ctx_out && d_ctx_out != ctx->lms_ctx_far) // context words from the key payload (0 = to be gathered)
             KCHECK(hipMemcpyAsync(d_ctx_out, ctx->lms_ctx_far, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     KTRY(kiss_radix_check(ctx));
@@ -202,15 +261,20 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
     const uint64_t m = m_far + near_count;
-    if (m > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
+    const bool in_place = d_far_sorted == ctx->lms_sorted_far; // views of the ctx's own buffers: nothing to copy
+    if (m > ctx->m_cap) {
+        if (in_place) return KISS_HIP_E_INVALID; // (kiss_hip_stage_reserve before the pieces are gathered)
+        KTRY(kiss_lms_reserve(ctx, m + m / 64 + 1024));
+    }
     if (m_far) {
-        KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        if (d_far_ctx)
+        if (!in_place)
+            KCHECK(hipMemcpyAsync(ctx->lms_sorted_far, d_far_sorted, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_far_ctx && d_far_ctx != ctx->lms_ctx_far)
             KCHECK(hipMemcpyAsync(ctx->lms_ctx_far, d_far_ctx, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        else // no context words came along: gather them all; nothing is known about ties either, so all are tainted
+        else if (!d_far_ctx) // no context words came along: gather them all; nothing is known about ties either, so all are tainted
             KCHECK(hipMemsetD32Async((hipDeviceptr_t)ctx->lms_ctx_far, (int)KISS_CTX_TAINT, m_far, ctx->stream));
     }
-    if (near_count) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
+    if (near_count && d_near_pos != ctx->lms_pos + m_far) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
         KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));
     for (int i = 0; i < 12; i++) ctx->counts[i] = counts12[i];
     ctx->m = m;

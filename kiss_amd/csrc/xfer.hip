@@ -21,14 +21,12 @@ namespace {
 
 constexpr int XF_MAX_THREADS = 16;
 // copy threads for pageable memory (each with two bounce buffers and a stream): KISS_HIP_XFER_THREADS, default 8
+// (read per call like every other hook; the pool below holds buffers for XF_MAX_THREADS and creates them on demand)
 static int xf_threads()
 {
-    static const int t = [] {
-        const char *e = getenv("KISS_HIP_XFER_THREADS");
-        const int v = e ? atoi(e) : 8;
-        return v < 1 ? 1 : (v > XF_MAX_THREADS ? XF_MAX_THREADS : v);
-    }();
-    return t;
+    const char *e = getenv("KISS_HIP_XFER_THREADS");
+    const int v = e ? atoi(e) : 8;
+    return v < 1 ? 1 : (v > XF_MAX_THREADS ? XF_MAX_THREADS : v);
 }
 #define XF_THREADS xf_threads()
 constexpr size_t XF_CHUNK = 16ull << 20;
@@ -46,8 +44,9 @@ bool host_is_pinned(const void *p)
 
 int xfer_pool(kiss_hip_ctx *ctx)
 {
-    if (ctx->xf_ready) return KISS_HIP_OK;
-    for (int t = 0; t < XF_THREADS; t++) { // (a call that failed half-way is resumed, not repeated)
+    const int want = XF_THREADS;
+    if (ctx->xf_ready >= want) return KISS_HIP_OK;
+    for (int t = 0; t < want; t++) { // (a call that failed half-way is resumed, not repeated)
         if (!ctx->xf_stream[t] && hipStreamCreateWithFlags(&ctx->xf_stream[t], hipStreamNonBlocking) != hipSuccess)
             return KISS_HIP_E_HIP;
         for (int b = 0; b < 2; b++) {
@@ -57,7 +56,7 @@ int xfer_pool(kiss_hip_ctx *ctx)
                 return KISS_HIP_E_HIP;
         }
     }
-    ctx->xf_ready = true;
+    ctx->xf_ready = want;
     return KISS_HIP_OK;
 }
 
@@ -201,7 +200,7 @@ static bool looks_untouched(uint64_t lo, uint64_t hi, uint64_t page)
 
 void *kiss_prefault_start(void *p, uint64_t bytes)
 {
-    static const bool off = getenv("KISS_HIP_NO_PREFAULT") != nullptr; // A-B hook
+    const bool off = getenv("KISS_HIP_NO_PREFAULT") != nullptr; // A-B hook (read per call)
     if (off || bytes < (64ull << 20)) return nullptr;
     const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
     const uint64_t lo = ((uint64_t)(uintptr_t)p + page - 1) / page * page, hi = ((uint64_t)(uintptr_t)p + bytes) / page * page;

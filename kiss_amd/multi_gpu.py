@@ -1,15 +1,20 @@
 """Sharded suffix sort across the GPUs of one node: one process per GPU, torch.distributed (RCCL) for the
 exchange, libkiss_hip.so stage calls for the arithmetic.  Design: SURVEY.md section 8(e), DESIGN.md section 7.
+(The same pipeline driven by ONE process with peer copies is kiss_hip_multi_* of the C ABI, kiss_amd/csrc/multi.hip.)
 
   every rank : text replicated; classify text slice r  -> local ascending LMS list (key32, pos)
-               all_reduce(13 counters), all_reduce(2^16-bin histogram of the first 16 key bits) -> G key ranges
-               stable partition by destination, all_to_all (counts, keys, positions)
-               k-ordered sort of the received key range
-  rank 0     : receives the sorted pieces (positions + context words) in key-range order and the near-end suffixes,
+               ONE small all-gather: 13 counters, list sizes, the near-end positions and the 2^14-bin histogram of the
+               first 14 key bits of every rank -> global counts, G key ranges balanced by LMS count, the G x G matrix
+               of piece sizes -- the only host read-back of the exchange phase
+               stable partition by destination, all_to_all (keys, positions) straight into the buffers the sort works on
+               k-ordered sort of the received key range, in place
+  rank 0     : receives the sorted pieces (positions + context words) in key-range order behind its own piece,
                runs placement + induction
 
-The only data-path collective is the all-to-all of the LMS list (12 bytes per LMS suffix) plus the gather of the
-sorted pieces (8 bytes per LMS suffix); induction is one global dependency chain and stays on one GPU.
+The only data-path collectives are the all-to-all of the LMS list (12 bytes per LMS suffix) and the gather of the
+sorted pieces (8 bytes per LMS suffix); induction is one global dependency chain and stays on one GPU.  No buffer is
+copied inside a rank: the stage calls work on views of the context's own arrays (kiss_hip_stage_view), and with one
+rank nothing moves at all.
 `Backend` abstracts the stage calls so the orchestration can be exercised on CPU (gloo) with a stand-in backend
 (tests/test_multi_gpu.py); the product backend is `GpuBackend` (no CPU fallback).
 """
@@ -22,10 +27,22 @@ from .sorter import _check
 
 HIST_BITS = 14   # 7 bases: the histogram is private to a workgroup in LDS (64 KiB), 16 384 bins split <= 64 key ranges finely enough
 EXACT_H0 = 256  # bounded order of the first phase when exact order falls back to rank doubling
+NEAR_INLINE = 1024  # near-end positions that ride in the fused all-gather (k = 256: about a hundred; more: one extra gather)
+
+
+class _DevArray:
+    """a raw device pointer as something torch.as_tensor wraps without a copy"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 class GpuBackend:
-    """stage calls on torch device tensors through the C ABI (include/kiss_hip.h, stage_* entry points)"""
+    """stage calls on torch device tensors through the C ABI (include/kiss_hip.h, stage_* entry points).  The tensors
+    handed between the stages are views of the context's own work arrays: no stage copies anything in or out."""
+
+    VIEW_TYPES = {_lib.VIEW_LOCAL_KEYS: "<i8", _lib.VIEW_LOCAL_POS: "<i4", _lib.VIEW_PART_KEYS: "<i8",
+                  _lib.VIEW_PART_POS: "<i4", _lib.VIEW_SORTED: "<i4", _lib.VIEW_SORTED_CTX: "<i4"}
 
     def __init__(self, ctx, S, k):
         import torch
@@ -34,12 +51,44 @@ class GpuBackend:
         self.n = int(S.numel())
         self.dev = S.device
         self.lib = _lib.load()
+        self._views = {}
 
     def _sync(self):
         # The library works on its own HIP stream and takes raw pointers: everything torch / RCCL has queued for
         # these buffers (collectives run on RCCL's streams and only order themselves against torch's current
         # stream) must have finished before a stage call reads them.  Stage calls return synchronised.
         self.torch.cuda.synchronize(self.dev)
+
+    def view(self, which, count):
+        """the first `count` entries of one of the context's work arrays as a tensor (zero-copy)"""
+        torch = self.torch
+        ptr, cap = ctypes.c_void_p(), ctypes.c_uint64()
+        _check(self.lib.kiss_hip_stage_view(self.ctx._ctx, which, ctypes.byref(ptr), ctypes.byref(cap)),
+               "kiss_hip_stage_view", self.ctx._ctx)
+        dt = torch.int64 if self.VIEW_TYPES[which] == "<i8" else torch.int32
+        if count == 0 or not ptr.value:
+            return torch.empty(0, dtype=dt, device=self.dev)
+        assert count <= cap.value, "view beyond the capacity of the work arrays (ensure_capacity first)"
+        key = (which, ptr.value, cap.value)
+        full = self._views.get(key)
+        if full is None:
+            self._views = {k_: v for k_, v in self._views.items() if k_[0] != which}  # the array was regrown: stale view
+            full = torch.as_tensor(_DevArray(ptr.value, cap.value, self.VIEW_TYPES[which]), device=self.dev)
+            self._views[key] = full
+        return full[:count]
+
+    def ensure_capacity(self, count):
+        """-> True when the work arrays had to regrow: their contents (the classified list) are lost, classify again"""
+        cap = ctypes.c_uint64()
+        ptr = ctypes.c_void_p()
+        _check(self.lib.kiss_hip_stage_view(self.ctx._ctx, _lib.VIEW_LOCAL_POS, ctypes.byref(ptr), ctypes.byref(cap)),
+               "kiss_hip_stage_view", self.ctx._ctx)
+        if count <= cap.value:
+            return False
+        self._sync()
+        _check(self.lib.kiss_hip_stage_reserve(self.ctx._ctx, int(count)), "kiss_hip_stage_reserve", self.ctx._ctx)
+        self._views = {}
+        return True
 
     def classify(self, lo, hi):
         self._sync()
@@ -49,17 +98,10 @@ class GpuBackend:
         return [int(x) for x in c]
 
     def local_lms(self):
-        torch = self.torch
         m, mf = ctypes.c_uint64(), ctypes.c_uint64()
         _check(self.lib.kiss_hip_stage_local_lms(self.ctx._ctx, None, None, ctypes.byref(m), ctypes.byref(mf)),
                "kiss_hip_stage_local_lms", self.ctx._ctx)
-        keys = torch.empty(m.value, dtype=torch.int64, device=self.dev)
-        pos = torch.empty(m.value, dtype=torch.int32, device=self.dev)
-        if m.value:
-            _check(self.lib.kiss_hip_stage_local_lms(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()),
-                                                     ctypes.c_void_p(pos.data_ptr()), ctypes.byref(m), ctypes.byref(mf)),
-                   "kiss_hip_stage_local_lms", self.ctx._ctx)
-        return keys, pos, int(mf.value)
+        return self.view(_lib.VIEW_LOCAL_KEYS, m.value), self.view(_lib.VIEW_LOCAL_POS, m.value), int(mf.value)
 
     def key_hist(self, keys, bits):
         self._sync()
@@ -71,23 +113,31 @@ class GpuBackend:
 
     def partition(self, keys, pos, bits, splitters, groups):
         self._sync()
-        torch = self.torch
-        ko, po = torch.empty_like(keys), torch.empty_like(pos)
+        count = int(keys.numel())
+        ko, po = self.view(_lib.VIEW_PART_KEYS, count), self.view(_lib.VIEW_PART_POS, count)
         sp = (ctypes.c_uint32 * max(1, groups - 1))(*[int(s) for s in splitters])
         _check(self.lib.kiss_hip_stage_partition(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()),
-                                                 ctypes.c_void_p(pos.data_ptr()), int(keys.numel()), bits, sp, groups,
+                                                 ctypes.c_void_p(pos.data_ptr()), count, bits, sp, groups,
                                                  ctypes.c_void_p(ko.data_ptr()), ctypes.c_void_p(po.data_ptr()), None),
                "kiss_hip_stage_partition", self.ctx._ctx)
         return ko, po
+
+    def recv_buffers(self, count):
+        """where the exchange delivers this rank's key range: the buffers stage_sort works on"""
+        return self.view(_lib.VIEW_LOCAL_KEYS, count), self.view(_lib.VIEW_LOCAL_POS, count)
+
+    def sorted_buffers(self, count):
+        """rank 0: where the sorted pieces are gathered (its own piece, the first key range, is there already)"""
+        return self.view(_lib.VIEW_SORTED, count), self.view(_lib.VIEW_SORTED_CTX, count)
 
     def sort(self, keys, pos):
         """-> (k-ordered positions, their context words from the key payload; 0 = to be gathered), or None when exact
         order was asked for and the ties are deeper than the 32-bases-per-round path handles (KISS_HIP_E_DEEP)"""
         self._sync()
-        out = self.torch.empty_like(pos)
-        cw = self.torch.empty_like(pos)
+        count = int(pos.numel())
+        out, cw = self.view(_lib.VIEW_SORTED, count), self.view(_lib.VIEW_SORTED_CTX, count)
         rc = self.lib.kiss_hip_stage_sort(self.ctx._ctx, ctypes.c_void_p(keys.data_ptr()), ctypes.c_void_p(pos.data_ptr()),
-                                          int(pos.numel()), self.n, self.k, ctypes.c_void_p(out.data_ptr()),
+                                          count, self.n, self.k, ctypes.c_void_p(out.data_ptr()),
                                           ctypes.c_void_p(cw.data_ptr()), None)
         if rc == _lib.KISS_HIP_E_DEEP:
             return None
@@ -140,6 +190,15 @@ class _Comm:
             t.copy_(h)
         return t
 
+    def all_gather_rows(self, row):
+        """row: 1-D int64 tensor of the same length on every rank -> numpy [world, len] on the host.  ONE collective and
+        ONE device-to-host read, however many small things the ranks have to tell each other."""
+        torch = self.torch
+        h = self._h(row).contiguous()
+        out = torch.empty(self.world * h.numel(), dtype=h.dtype, device=h.device)
+        self.dist.all_gather_into_tensor(out, h, group=self.group)
+        return out.cpu().numpy().reshape(self.world, h.numel())
+
     def all_gather_ints(self, value):
         t = self.torch.tensor([int(value)], dtype=self.torch.int64)
         out = [self.torch.zeros(1, dtype=self.torch.int64) for _ in range(self.world)]
@@ -152,16 +211,12 @@ class _Comm:
 
     def all_to_all_counts(self, send_counts):
         """-> (recv_counts, largest count of the whole G x G matrix).  The full matrix is all-gathered (G^2 integers)
-        so that every rank derives the SAME transport decision from it in all_to_all()."""
-        s = self.torch.tensor([int(c) for c in send_counts], dtype=self.torch.int64)
-        rows = [self.torch.zeros(self.world, dtype=self.torch.int64) for _ in range(self.world)]
-        if not self.stage:
-            dev = self.torch.device("cuda", self.torch.cuda.current_device())
-            s = s.to(dev)
-            rows = [r.to(dev) for r in rows]
-        self.dist.all_gather(rows, s, group=self.group)
-        mat = [[int(x) for x in row.tolist()] for row in rows]
-        return [mat[src][self.rank] for src in range(self.world)], max(max(row) for row in mat)
+        so that every rank derives the SAME transport decision from it in all_to_all().  (The sort itself derives the
+        matrix from the all-gathered histograms, sharded_suffix_sort; this stays for callers that only know their row.)"""
+        mat = self.all_gather_rows(self.torch.tensor([int(c) for c in send_counts], dtype=self.torch.int64,
+                                                     device=None if self.stage else
+                                                     self.torch.device("cuda", self.torch.cuda.current_device())))
+        return [int(mat[src][self.rank]) for src in range(self.world)], int(mat.max())
 
     def use_collective(self, esz, largest_count):
         """One decision for all ranks: a single all_to_all_single only if EVERY pair's message fits MAX_MSG_BYTES
@@ -218,20 +273,27 @@ class _Comm:
         out.copy_(hout)
         return out
 
-    def gather_to_root(self, piece, counts, make_empty):
+    def gather_to_root(self, piece, counts, make_empty, out=None):
         """variable-size gather in rank order; returns the concatenation on rank 0, None elsewhere.
+        out (rank 0, optional): the destination, sum(counts) entries; when its head IS rank 0's own piece (the views of
+        GpuBackend) nothing is copied for it.
         RCCL: all receives are posted at once (batch_isend_irecv), so the seven xGMI links into rank 0 carry their
         pieces concurrently instead of one after the other; messages stay below MAX_MSG_BYTES."""
+        total = int(sum(counts))
+        c0 = int(counts[0])
+
+        def own(dst):
+            if c0 and dst[:c0].data_ptr() != piece.data_ptr():
+                dst[:c0] = piece
         if self.stage:  # gloo (tests): through host memory, one source at a time
             if self.rank == 0:
-                total = int(sum(counts))
-                out = make_empty(total, piece.dtype)
-                off = 0
-                for src in range(self.world):
+                if out is None:
+                    out = make_empty(total, piece.dtype)
+                own(out)
+                off = c0
+                for src in range(1, self.world):
                     c = int(counts[src])
-                    if src == 0:
-                        out[off:off + c] = piece
-                    elif c:
+                    if c:
                         buf = self.torch.empty(c, dtype=piece.dtype)
                         self.dist.recv(buf, src, group=self.group)
                         out[off:off + c] = buf.to(out.device)
@@ -242,20 +304,18 @@ class _Comm:
             return None
         step = max(1, self.MAX_MSG_BYTES // piece.element_size())
         ops = []
-        out = None
         if self.rank == 0:
-            total = int(sum(counts))
-            out = make_empty(total, piece.dtype)
-            off = 0
-            for src in range(self.world):
+            if out is None:
+                out = make_empty(total, piece.dtype)
+            own(out)
+            off = c0
+            for src in range(1, self.world):
                 c = int(counts[src])
-                if src == 0:
-                    out[off:off + c] = piece
-                else:
-                    for a in range(0, c, step):
-                        ops.append(self.dist.P2POp(self.dist.irecv, out[off + a:off + min(c, a + step)], src, self.group))
+                for a in range(0, c, step):
+                    ops.append(self.dist.P2POp(self.dist.irecv, out[off + a:off + min(c, a + step)], src, self.group))
                 off += c
         else:
+            out = None
             piece = piece.contiguous()
             for a in range(0, int(piece.numel()), step):
                 ops.append(self.dist.P2POp(self.dist.isend, piece[a:a + step], 0, self.group))
@@ -307,35 +367,65 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
         timings[name] = timings.get(name, 0.0) + 1e3 * (now - _t[0])
         _t[0] = now
     counts = backend.classify(lo, hi)
-    phase("classify")
     keys, pos, m_far = backend.local_lms()
+    phase("classify")
     m_local = int(pos.numel())
-    # global counters (sum of the windowed ones)
-    ct = torch.tensor(counts, dtype=torch.int64, device=keys.device)
-    comm.all_reduce(ct)
-    counts12 = [int(x) for x in ct[:12].tolist()]
+    bins = 1 << HIST_BITS
+    # ---- what the ranks have to tell each other before the exchange, in ONE all-gather and ONE host read:
+    #      [13 counters | m_local | m_far | NEAR_INLINE near-end positions | 2^14-bin key histogram (G > 1)]
+    near_local = m_local - m_far
+    head = torch.zeros(15 + NEAR_INLINE, dtype=torch.int64)
+    head[:13] = torch.tensor(counts, dtype=torch.int64)
+    head[13], head[14] = m_local, m_far
+    row = head.to(keys.device)
+    if 0 < near_local <= NEAR_INLINE:
+        row[15:15 + near_local] = pos[m_far:].to(torch.int64)
+    if G > 1:
+        row = torch.cat([row, backend.key_hist(keys[:m_far], HIST_BITS)])
+    rows = comm.all_gather_rows(row)
+    counts12 = [int(x) for x in rows[:, :12].sum(axis=0)]
+    m_locals, m_fars = rows[:, 13].astype(np.int64), rows[:, 14].astype(np.int64)
+    near_counts = [int(x) for x in (m_locals - m_fars)]
+    m_far_total, near_total = int(m_fars.sum()), int(sum(near_counts))
     # near-end suffixes (only the rank(s) owning the end of the text have any) go to rank 0 as they are
-    near_counts = comm.all_gather_ints(m_local - m_far)
-    near_all = comm.gather_to_root(pos[m_far:], near_counts, backend.empty)
-    phase("counters + near-end gather")
+    if max(near_counts) <= NEAR_INLINE:
+        near_all = None
+        if r == 0:
+            near_np = np.concatenate([rows[q, 15:15 + near_counts[q]] for q in range(G)]).astype(np.int32)
+            near_all = torch.from_numpy(near_np).to(keys.device) if near_np.size else backend.empty(0, torch.int32)
+    else:  # a k in the thousands and beyond: one extra gather (every rank takes this branch alike)
+        near_all = comm.gather_to_root(pos[m_far:].clone(), near_counts, backend.empty)
+    phase("counters + near-end + histograms (one all-gather)")
+    # key ranges balanced by LMS count; the G x G matrix of piece sizes follows from every rank's histogram
+    if G > 1:
+        hists = rows[:, 15 + NEAR_INLINE:15 + NEAR_INLINE + bins].astype(np.int64)
+        splitters = choose_splitters(hists.sum(axis=0), G)
+        mat = [group_counts(hists[q], splitters, G) for q in range(G)]
+    else:
+        splitters, mat = [], [[m_far]]
+    send_counts = mat[r]
+    recv_counts = [mat[q][r] for q in range(G)]
+    piece_counts = [int(sum(mat[q][g] for q in range(G))) for g in range(G)]
+    largest = max(max(row_) for row_ in mat)
+    R = piece_counts[r]
+    # capacity of the work arrays: this rank's received list, and on rank 0 the whole sorted list + the near-end suffixes
+    need = max(R, m_far_total + near_total) if r == 0 else R
+    if hasattr(backend, "ensure_capacity") and backend.ensure_capacity(need):
+        backend.classify(lo, hi)  # the regrown arrays lost the list: classify the slice again (skewed key ranges, (AC)^n)
+        keys, pos, m_far = backend.local_lms()
     keys, pos = keys[:m_far], pos[:m_far]
-    # key ranges balanced by LMS count
-    hist = backend.key_hist(keys, HIST_BITS)
-    local_hist = hist.cpu().numpy().copy()
-    comm.all_reduce(hist)
-    splitters = choose_splitters(hist.cpu().numpy(), G)
-    send_counts = group_counts(local_hist, splitters, G)
-    phase("key histogram + splitters")
-    skeys, spos = backend.partition(keys, pos, HIST_BITS, splitters, G)
-    phase("partition")
-    # the exchange: all-to-all of (key, position), receiver keeps source-rank order
-    recv_counts, largest = comm.all_to_all_counts(send_counts)
-    R = int(sum(recv_counts))
-    rkeys = backend.empty(R, torch.int64)
-    rpos = backend.empty(R, torch.int32)
-    comm.all_to_all(rkeys, skeys, recv_counts, send_counts, largest)
-    comm.all_to_all(rpos, spos, recv_counts, send_counts, largest)
-    phase("exchange")
+    phase("splitters")
+    if G > 1:
+        skeys, spos = backend.partition(keys, pos, HIST_BITS, splitters, G)
+        phase("partition")
+        # the exchange: all-to-all of (key, position) into the buffers the sort works on, receiver keeps source-rank order
+        rkeys, rpos = backend.recv_buffers(R) if hasattr(backend, "recv_buffers") else (backend.empty(R, torch.int64),
+                                                                                       backend.empty(R, torch.int32))
+        comm.all_to_all(rkeys, skeys, recv_counts, send_counts, largest)
+        comm.all_to_all(rpos, spos, recv_counts, send_counts, largest)
+        phase("exchange")
+    else:  # one rank: the classified list IS the list to sort, where it is
+        rkeys, rpos = keys, pos
     res = backend.sort(rkeys, rpos)
     phase("sort")
     if int(backend.k) >= n:
@@ -359,12 +449,15 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
     elif res is None:
         raise RuntimeError("kiss_hip_stage_sort: unexpected KISS_HIP_E_DEEP for a bounded k")
     sorted_piece, piece_ctx = res
-    piece_counts = comm.all_gather_ints(R)
-    far_all = comm.gather_to_root(sorted_piece, piece_counts, backend.empty)
     # the context words travel with the pieces (4 more bytes per LMS suffix over xGMI instead of a random text
-    # gather per LMS suffix on rank 0)
-    ctx_all = comm.gather_to_root(piece_ctx, piece_counts, backend.empty)
-    phase("gather")
+    # gather per LMS suffix on rank 0); rank 0's own piece -- the first key range -- is where it belongs already
+    if G > 1:
+        dst = backend.sorted_buffers(m_far_total) if (r == 0 and hasattr(backend, "sorted_buffers")) else (None, None)
+        far_all = comm.gather_to_root(sorted_piece, piece_counts, backend.empty, out=dst[0])
+        ctx_all = comm.gather_to_root(piece_ctx, piece_counts, backend.empty, out=dst[1])
+        phase("gather")
+    else:
+        far_all, ctx_all = sorted_piece, piece_ctx
     out = None
     if r == 0:
         out = backend.induce(far_all, near_all, counts12, SA, far_ctx=ctx_all)

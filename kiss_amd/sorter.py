@@ -31,19 +31,37 @@ def _check(status, where, ctx=None):
 class Context:
     """Device workspace for texts up to max_n bases on one GPU (kiss_hip_ctx)."""
 
-    def __init__(self, max_n, device=0, profiling=False):
+    def __init__(self, max_n, device=0, profiling=False, lms_capacity=0):
+        """lms_capacity (optional): capacity of the per-LMS-suffix work arrays instead of 0.32 max_n -- a rank > 0 of a
+        sharded sort holds about 1/G of the LMS suffixes (kiss_hip_ctx_create_sized; the arrays regrow on demand)"""
         self._lib = _lib.load()
         self._ctx = ctypes.c_void_p()
-        _check(self._lib.kiss_hip_ctx_create(ctypes.byref(self._ctx), int(device), int(max_n)), "kiss_hip_ctx_create")
+        _check(self._lib.kiss_hip_ctx_create_sized(ctypes.byref(self._ctx), int(device), int(max_n), int(lms_capacity)),
+               "kiss_hip_ctx_create_sized")
+        self._owned = True
         self.max_n = int(max_n)
         self.device = int(device)
         if profiling:
             self.set_profiling(True)
 
+    @classmethod
+    def _borrowed(cls, handle, max_n, device):
+        """a kiss_hip_ctx owned by something else (a MultiContext's per-device context): never destroyed from here"""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p(handle)
+        self._owned = False
+        self.max_n, self.device = int(max_n), int(device)
+        return self
+
     def close(self):
-        if self._ctx:
+        if self._ctx and self._owned:
             self._lib.kiss_hip_ctx_destroy(self._ctx)
-            self._ctx = ctypes.c_void_p()
+        self._ctx = ctypes.c_void_p()
+
+    def release_io_buffers(self):
+        """gives back the device-side copies of the caller's buffers the host-pointer entry points keep between calls"""
+        _check(self._lib.kiss_hip_ctx_release_io_buffers(self._ctx), "kiss_hip_ctx_release_io_buffers", self._ctx)
 
     def __enter__(self):
         return self
@@ -147,6 +165,63 @@ class Context:
         return asc, srt, counts
 
 
+class MultiContext:
+    """Several GPUs of one node driven by THIS process (kiss_hip_multi, include/kiss_hip.h): the LMS sort sharded by key
+    range over `devices`, peer copies over xGMI, induction on devices[0].  A device may be listed more than once."""
+
+    def __init__(self, devices, max_n):
+        self._lib = _lib.load()
+        self._mc = ctypes.c_void_p()
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        _check(self._lib.kiss_hip_multi_create(ctypes.byref(self._mc), arr, len(self.devices), int(max_n)),
+               "kiss_hip_multi_create")
+        self.max_n = int(max_n)
+
+    def close(self):
+        if self._mc:
+            self._lib.kiss_hip_multi_destroy(self._mc)
+            self._mc = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rank_context(self, rank=0):
+        """the per-device context of one share (statistics, profiling switches); owned by this object"""
+        h = self._lib.kiss_hip_multi_ctx(self._mc, int(rank))
+        if not h:
+            raise IndexError("no such share")
+        return Context._borrowed(h, self.max_n, self.devices[rank])
+
+    def suffix_sort(self, S, k=256, algo=_lib.ALGO_PARALLEL_SORTING):
+        S = np.ascontiguousarray(S, dtype=np.uint8)
+        SA = np.empty(S.size + 1, dtype=np.uint32)
+        _check(self._lib.kiss_hip_multi_suffix_sort_dna_u32(self._mc, S.ctypes.data if S.size else None, S.size,
+                                                            int(k) & 0xFFFFFFFF, int(algo), SA.ctypes.data),
+               "kiss_hip_multi_suffix_sort_dna_u32")
+        return SA
+
+    def suffix_sort_dev(self, d_S_ptr, n, d_SA_ptr, k=256, algo=_lib.ALGO_PARALLEL_SORTING):
+        """d_S / d_SA: raw device pointers on devices[0]"""
+        _check(self._lib.kiss_hip_multi_suffix_sort_dna_u32_dev(self._mc, ctypes.c_void_p(d_S_ptr), int(n),
+                                                                int(k) & 0xFFFFFFFF, int(algo), ctypes.c_void_p(d_SA_ptr)),
+               "kiss_hip_multi_suffix_sort_dna_u32_dev")
+
+    def stats(self):
+        st = _lib.MultiStats()
+        _check(self._lib.kiss_hip_multi_get_stats(self._mc, ctypes.byref(st)), "kiss_hip_multi_get_stats")
+        return st.as_dict()
+
+
 FNV1A64_SEED = 0xcbf29ce484222325
 
 
@@ -172,10 +247,17 @@ class KISS1Sorter:
         return np.ascontiguousarray(np.asarray(seq, dtype=np.uint8))
 
     @classmethod
-    def get_suffix_array_dna(cls, S, k=256, num_threads=None, device=0):
+    def get_suffix_array_dna(cls, S, k=256, num_threads=None, device=0, devices=None):
+        """devices (optional): shard the LMS sort over these GPUs (kiss_hip_suffix_sort_dna_u32_multi)"""
         S = cls.prepare_aligned_ref(S)
         SA = np.empty(S.size + 1, dtype=np.uint32)
         lib = _lib.load()
+        if devices is not None:
+            arr = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib.kiss_hip_suffix_sort_dna_u32_multi(S.ctypes.data, S.size, int(k) & 0xFFFFFFFF, cls.algo,
+                                                          SA.ctypes.data, arr, len(devices)),
+                   "kiss_hip_suffix_sort_dna_u32_multi")
+            return SA
         _check(lib.kiss_hip_suffix_sort_dna_u32(S.ctypes.data, S.size, int(k) & 0xFFFFFFFF, cls.algo, SA.ctypes.data,
                                                 int(device)), "kiss_hip_suffix_sort_dna_u32")
         return SA

@@ -60,18 +60,37 @@ RECIPES = [
     ["periodic", 600_000, 2052, 26, 6000],      # higher-order-repeat-like array: a 2052-base unit at 1 % divergence
     ["genome_like", 3_000_000, 31],
     ["iid", 60_000, 51], ["iid", 30_000, 52], ["genome_like", 400_000, 53],   # k so large that a third of the LMS
-]                                                                               # suffixes are near-end (KS below)
+    # suffixes are near-end (KS below)
+    # round 3: BASELINE.json configs[0] -- `suffix_sort example/drosophia_chr1_2.fa -k 256 -t 24` (reference README.md:85-88):
+    # n = 48 800 648, the C1 stand-in of SURVEY.md section 8(d) (seed 1), pinned at the config's 24 threads
+    ["genome_like", 48_800_648, 1],
+]
 # orders other than the default (32, 256, exact) for a recipe
 KS = {("iid", 60_000, 51): (20_000,), ("iid", 30_000, 52): (10_000, 29_000), ("genome_like", 400_000, 53): (100_000,)}
+# reference thread count other than the default 8 for a recipe (OpenMP oversubscribes where the host has fewer cores;
+# KISS1's result does not depend on it)
+THREADS = {("genome_like", 48_800_648, 1): 24}
 
 if __name__ == "__main__":
+    # --append: keep the pins already in ref_pins.json, compute only the (recipe, k) pairs that are missing
+    append = "--append" in sys.argv[1:]
+    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_pins.json")
     orc, ref = oracle_binding.load(), ref_binding.load()
     T = min(8, ref.max_threads())
     pins = []
     T_all = T
+    have = set()
+    if append and os.path.exists(out_path):
+        with open(out_path) as f:
+            old = json.load(f)
+        pins, T_all = old["pins"], old.get("threads", T)
+        have = {(tuple(p["recipe"]), p["k"]) for p in pins}
     for recipe in RECIPES:
+        ks = KS.get(tuple(recipe), (256,) if recipe[1] > 5_000_000 else (32, 256, 0xFFFFFFFF))
+        if all((tuple(recipe), int(k)) in have for k in ks):
+            continue
         S = make_input(recipe)
-        T = T_all
+        T = THREADS.get(tuple(recipe), T_all)
         lms_asc, _ = ref.get_lms(S, T)
         if not np.array_equal(lms_asc, orc.get_lms(S)[0]):
             # seen on (TC)^n, n = 300 000: at the maximal LMS density (every other position) the reference's get_lms
@@ -81,8 +100,9 @@ if __name__ == "__main__":
             lms_asc, _ = ref.get_lms(S, T)
             print("NOTE: reference get_lms is thread-count dependent on", recipe, "-- pinned at 1 thread", flush=True)
         assert np.array_equal(lms_asc, orc.get_lms(S)[0]), recipe
-        ks = KS.get(tuple(recipe), (256,) if S.size > 5_000_000 else (32, 256, 0xFFFFFFFF))
         for k in ks:
+            if (tuple(recipe), int(k)) in have:
+                continue
             sa_o, lms_o = orc.suffix_sort(S, k, stages=True)
             sa_r, lms_r = ref.suffix_sort(S, k, T=T, stages=True)                # restated LMS sort + reference induction
             sa_r2 = ref.suffix_sort(S, k, T=T, sorted_lms=lms_o)                  # reference code only, oracle's LMS order
@@ -91,6 +111,6 @@ if __name__ == "__main__":
                          "lms_asc_fnv": "%016x" % orc.fnv(lms_asc), "lms_sorted_fnv": "%016x" % orc.fnv(lms_r),
                          "sa_fnv": "%016x" % orc.fnv(sa_r)})
             print(recipe, k, pins[-1]["sa_fnv"], flush=True)
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_pins.json"), "w") as f:
+    with open(out_path, "w") as f:
         json.dump({"made_by": "tests/golden/make_ref_golden.py", "threads": T_all, "pins": pins}, f, indent=1)
     print("wrote", len(pins), "pins")

@@ -65,6 +65,7 @@ def test_ctypes_structs_match_the_header():
     assert ctypes.sizeof(_lib.Stats) == _sizeof_from_header("kiss_hip_stats")
     assert ctypes.sizeof(_lib.VerifyReport) == _sizeof_from_header("kiss_hip_verify_report")
     assert ctypes.sizeof(_lib.FmiView) == _sizeof_from_header("kiss_hip_fmi_view")
+    assert ctypes.sizeof(_lib.MultiStats) == _sizeof_from_header("kiss_hip_multi_stats")
     # and the field the Python side reads last sits where the header puts it
     assert _lib.Stats.ms_refine.offset == ctypes.sizeof(_lib.Stats) - 16
 

@@ -524,3 +524,74 @@ def test_host_entry_into_a_destination_that_was_never_touched(monkeypatch):
         fresh2 = np.empty(S.size + 1, dtype=np.uint32)
         c.suffix_sort_host(S, fresh2, k=256)
         assert np.array_equal(fresh2, warm)
+        monkeypatch.setenv("KISS_HIP_NO_PREFAULT", "1")  # helpers switched off (the hook is read per call): the copy takes the faults
+        fresh3 = np.empty(S.size + 1, dtype=np.uint32)
+        c.suffix_sort_host(S, fresh3, k=256)
+        assert np.array_equal(fresh3, warm)
+        monkeypatch.delenv("KISS_HIP_NO_PREFAULT")
+        monkeypatch.setenv("KISS_HIP_XFER_THREADS", "3")  # (read per call as well; the pool grows on demand)
+        fresh4 = np.empty(S.size + 1, dtype=np.uint32)
+        c.suffix_sort_host(S, fresh4, k=256)
+        assert np.array_equal(fresh4, warm)
+        # the ctx keeps its device-side copies of S / SA between calls; they can be handed back
+        before = c.workspace_bytes()
+        c.release_io_buffers()
+        assert before - c.workspace_bytes() == 5 * c.max_n + 4
+        c.suffix_sort_host(S, fresh4, k=256)
+        assert np.array_equal(fresh4, warm) and c.workspace_bytes() == before
+
+
+def test_more_than_a_million_near_end_suffixes(oracle):
+    # a bounded k of several million bases: E = #LMS suffixes with fewer than D bases left passes 2^20, where the tie
+    # marking of the near-end rule used to ask for a grid of 2^32 threads ("invalid configuration argument"); the
+    # reference takes any k (kiss1_core.hpp:94-135).  i.i.d. text: the comparisons of the oracle end after a few bases.
+    import kiss_amd
+    S = gen.iid(4_400_000, 123)
+    k = 4_000_000
+    want = oracle.suffix_sort(S, k)
+    with kiss_amd.Context(max_n=S.size, device=0) as c:
+        sa = c.suffix_sort(S, k)
+        assert c.stats()["near_end"] > (1 << 20)
+        assert np.array_equal(sa, want)
+
+
+@pytest.mark.parametrize("shape", ["tandem", "near_end_ties", "all_tied", "genome"])
+def test_exact_order_taint_shortcut_equals_comparing_every_pair(oracle, monkeypatch, shape):
+    # the exact-order finish looks for tie groups only among TAINTED neighbours (suffixes whose place after the bounded
+    # phase may be the tie rule's); KISS_HIP_NO_TAINT compares every adjacent pair of the 256-ordered SA instead.  Same
+    # suffix array both ways, through the single call, through stage_refine_exact of the sharded form and through the
+    # multi-device entry.
+    import torch
+    import kiss_amd
+    from kiss_amd import multi_gpu
+    if shape == "tandem":
+        S = gen.periodic(600_000, 171, 5, mutations=300)
+    elif shape == "near_end_ties":  # the text ends inside a long exact repeat: near-end suffixes tie with far ones
+        base = gen.iid(300_000, 8)
+        S = np.concatenate([base, base[:120_000]])
+    elif shape == "all_tied":
+        S = np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 50_000)
+    else:
+        S = gen.genome_like(1_500_000, 21)
+    want = oracle.suffix_sort(S, 0xFFFFFFFF)
+    n = S.size
+    for no_taint in (False, True):
+        if no_taint:
+            monkeypatch.setenv("KISS_HIP_NO_TAINT", "1")
+        else:
+            monkeypatch.delenv("KISS_HIP_NO_TAINT", raising=False)
+        with kiss_amd.Context(max_n=n, device=0) as c:
+            assert np.array_equal(c.suffix_sort(S, 0xFFFFFFFF, algo=1), want)
+            # sharded form: k = 256 through the stages, then stage_refine_exact
+            dev = torch.device("cuda", 0)
+            d_S = torch.from_numpy(S).to(dev)
+            be = multi_gpu.GpuBackend(c, d_S, 256)
+            counts = be.classify(0, n)
+            keys, pos, m_far = be.local_lms()
+            srt, cw = be.sort(keys[:m_far], pos[:m_far])
+            SA = be.induce(srt, pos[m_far:].clone(), counts[:12], far_ctx=cw)
+            be.refine_exact(SA, 256)
+            assert np.array_equal(SA.cpu().numpy().view(np.uint32), want)
+        with kiss_amd.MultiContext([0, 0], max_n=n) as mc:
+            assert np.array_equal(mc.suffix_sort(S, 0xFFFFFFFF, algo=1), want)
+    monkeypatch.delenv("KISS_HIP_NO_TAINT", raising=False)
