@@ -257,21 +257,26 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
     f._context(max(f.N, 4 * Q)).set_profiling(True)
     r = f.query_batch(None, want_offsets=False, d_patterns=d_p)
     torch.cuda.synchronize()
-    kms0 = f._ctx.stats()["kernels"]["fm_query"]["ms"]
+    st0 = f._ctx.stats()
+    kms0 = st0["kernels"]["fm_query"]["ms"]
     t0 = time.perf_counter()
     for _ in range(steps):
         r = f.query_batch(None, want_offsets=False, d_patterns=d_p)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    kernel_s = 1e-3 * (f._ctx.stats()["kernels"]["fm_query"]["ms"] - kms0) / steps
+    st1 = f._ctx.stats()
+    kernel_s = 1e-3 * (st1["kernels"]["fm_query"]["ms"] - kms0) / steps
+    range_ms = (st1["ms_fm_range"] - st0["ms_fm_range"]) / steps
+    locate_ms = (st1["ms_fm_locate"] - st0["ms_fm_locate"]) / steps
     hits = r["total_hits"]
     index_bytes = sum(int(getattr(f, a).numel() * getattr(f, a).element_size()) for a in ("bwt", "occ1", "occ2", "sa", "b", "b_occ"))
     own = 48.0 * L * Q + 8.0 * hits          # this formulation: 2 LF steps of 24 B per character; range-wise locate
     survey = 48.0 * L * Q + 64.0 * hits      # 1 536 B + 64 B per hit for a 32-base pattern
     IC_GATHER_GBS = 8600.0  # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows (Infinity Cache)
+    range_bytes = 2.0 * L * 32.0 * Q  # backward search: 2 L occ per pattern, ONE 32-byte interleaved block each
     out = {"metric": "FM-index queries/sec (batched get_range + get_offsets, %d-base patterns)" % L,
            "value": Q * steps / el, "unit": "queries/s", "queries": Q, "steps": steps, "ms_per_step": 1e3 * el / steps,
-           "kernel_ms_per_step": 1e3 * kernel_s, "hits": hits, "checksum": r["checksum"], "index_n": n,
+           "kernel_ms_per_step": 1e3 * kernel_s, "range_kernel_ms": range_ms, "locate_kernel_ms": locate_ms, "hits": hits, "checksum": r["checksum"], "index_n": n,
            "index_bytes": index_bytes,
            "roofline": {"bound": "infinity_cache", "peak": IC_GATHER_GBS, "unit": "GB/s",
                         "peak_source": "MI355X_MICROARCH.md, gather of uniformly random rows from a 38 MB table",
@@ -279,6 +284,12 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
                                 "rate; every LF step is a dependent random 64-byte-sector read" % (index_bytes / 1e6),
                         "achieved_own_model": own / kernel_s / 1e9, "frac_own_model": own / kernel_s / 1e9 / IC_GATHER_GBS,
                         "own_model": "48 L per pattern + 8 B per hit",
+                        "range_kernel": {"bytes": range_bytes, "model": "2 L occ per pattern x one 32-byte block (k_fm_range)",
+                                         "achieved": range_bytes / max(1e-9, 1e-3 * range_ms) / 1e9,
+                                         "frac": range_bytes / max(1e-9, 1e-3 * range_ms) / 1e9 / IC_GATHER_GBS},
+                        "locate_kernel": {"bytes": 8.0 * hits, "model": "4 B sampled-SA read + 4 B offset write per hit",
+                                          "achieved": 8.0 * hits / max(1e-9, 1e-3 * locate_ms) / 1e9,
+                                          "frac": 8.0 * hits / max(1e-9, 1e-3 * locate_ms) / 1e9 / IC_GATHER_GBS},
                         "achieved_survey_8d_model": survey / kernel_s / 1e9,
                         "frac_survey_8d_model": survey / kernel_s / 1e9 / IC_GATHER_GBS,
                         "survey_8d_model": "48 L per pattern + 64 B per hit"}}
@@ -325,6 +336,8 @@ def cpu_baseline(S_host_sample, k, threads=24):
 
 
 EXIT_TOO_FEW_DEVICES = 3  # a rank found fewer visible GPUs than --gpus: never retried, never a silent 1-GPU number
+EXIT_VERIFY_FAILED = 4    # the last suffix array failed the device-side check or differs from the pinned hash
+DM_N = 48_800_648         # drosophia_chr1_2 (reference README.md:88): BASELINE.json configs[0] / configs[2]
 
 
 def free_port():
@@ -337,7 +350,8 @@ def free_port():
 def launch_ranks(n_ranks, argv, child_cmd=None, timeout=None):
     """Starts n_ranks fresh processes of this script (or `child_cmd`, a test stub), one per LOCAL_RANK, waits for all,
     and returns (worst exit status, rank 0's stdout).  The parent never imports torch and never touches HIP.  As soon
-    as one rank exits non-zero the others are terminated (they would otherwise wait in a collective)."""
+    as one rank exits non-zero the others are terminated (they would otherwise wait in a collective); ranks that are all
+    alive but stuck (a collective that never completes) are terminated after `timeout` seconds -> status 124."""
     import subprocess
     port = free_port()
     cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
@@ -378,9 +392,7 @@ def launch_ranks(n_ranks, argv, child_cmd=None, timeout=None):
             live.clear()
             break
         if live:
-            if procs[0].stdout is not None and 0 in live:
-                pass  # rank 0 prints one line at the very end: read after exit (pipe buffer is ample)
-            time.sleep(0.05)
+            time.sleep(0.05)  # rank 0 prints one line at the very end: read after exit (the pipe buffer is ample)
     if procs[0].stdout is not None:
         try:
             out0 = procs[0].stdout.read()
@@ -391,22 +403,188 @@ def launch_ranks(n_ranks, argv, child_cmd=None, timeout=None):
 
 def parent_main(args, argv, child_cmd=None):
     """--gpus N > 1 without a launcher: be the launcher."""
-    rc, out0 = launch_ranks(args.gpus, argv, child_cmd=child_cmd)
-    if rc == 0:
+    timeout = getattr(args, "rank_timeout", None) or None
+    rc, out0 = launch_ranks(args.gpus, argv, child_cmd=child_cmd, timeout=timeout)
+    if rc in (0, EXIT_VERIFY_FAILED):  # a line whose SA failed its check is relayed as it is (value null) with the status
         sys.stdout.write(out0)
         sys.stdout.flush()
-        return 0
-    if rc != EXIT_TOO_FEW_DEVICES and args.mode == "sharded" and not args.no_fallback:
+        return rc
+    if rc not in (EXIT_TOO_FEW_DEVICES, 124) and args.mode == "sharded" and not args.no_fallback:
+        # (never after a timeout: ranks stuck in a collective say nothing a second set of ranks could use)
         reason = "sharded run failed (a rank exited with status %d, see stderr)" % rc
         print("[bench] %s; starting a fresh set of ranks with --mode replicas" % reason, file=sys.stderr, flush=True)
         rc2, out0 = launch_ranks(args.gpus, list(argv) + ["--mode", "replicas", "--sharded-error", reason],
-                                 child_cmd=child_cmd)
-        if rc2 == 0:
+                                 child_cmd=child_cmd, timeout=timeout)
+        if rc2 in (0, EXIT_VERIFY_FAILED):
             sys.stdout.write(out0)
             sys.stdout.flush()
-            return 0
         return rc2
     return rc
+
+
+def roofline_of(agg, prof_agg, steps, prof_steps, profile_all):
+    """roofline object of the dominant kernel class: ALGORITHMIC bytes per launch / average launch duration from the HIP
+    events of the library.  agg: {class: {ms, launches, items}} of the timed region (only the classes timed inside it),
+    prof_agg: the full breakdown (the same dict when every class is timed inside the region)."""
+    if not prof_agg or not any(v["launches"] for v in prof_agg.values()):
+        return None
+    name = max(prof_agg.items(), key=lambda kv: kv[1]["ms"])[0]
+    in_timed_region = bool(agg.get(name, {}).get("launches"))
+    a = agg[name] if in_timed_region else prof_agg[name]
+    a_steps = steps if in_timed_region else prof_steps
+    if not a["launches"] or a["ms"] <= 0:
+        return None
+    bytes_per_launch = ALGO_BYTES.get(name, 0.0) * a["items"] / a["launches"]
+    avg_s = 1e-3 * a["ms"] / a["launches"]
+    achieved = bytes_per_launch / avg_s / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": (bytes_per_launch * MEASURED_TRAFFIC_PER_ALGO_BYTE[name]
+                        if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
+            "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
+                            "kernel (separate rocprofv3 --pmc runs, profiles/r02_pmc_*.csv)",
+            "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / a_steps,
+            "measured_in": ("timed region (HIP events around this class only)" if in_timed_region and not profile_all else
+                            "timed region (HIP events around every class)" if in_timed_region else
+                            "profiled steps after the timed region (not the class timed inside it)"),
+            "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
+            "kernel_ms_per_step": {kn: kv["ms"] / prof_steps for kn, kv in prof_agg.items() if kv["launches"]},
+            "kernel_ms_per_step_from": ("timed region" if prof_agg is agg else
+                                        "%d extra steps with every class timed" % prof_steps)}
+
+
+def assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof_steps, stage, last_stats, workspace_bytes,
+                  phase_ms=None, sharded_error=None, data="synthetic", text_desc=None):
+    """The result line of rank 0 from what the timed region measured -- the same fields at every N (tests/
+    test_bench_launcher.py checks the N = 2 form on CPU).  `value` is the whole-job aggregate."""
+    total_bases = float(n) * args.steps * (1 if sharded else world)
+    if text_desc is None:
+        text_desc = "i.i.d." if args.iid else ("genome-like synthetic, HARSH satellite profile" if args.harsh
+                                               else "genome-like synthetic")
+    # one text sharded over the GPUs is the default form of this bench: the per-GPU work shrinks as N grows ("strong");
+    # the N = 1 line of that series says so too.  --mode replicas (one independent text per GPU) is the weak form.
+    strong = sharded or (world == 1 and args.mode == "sharded")
+    out = {
+        "metric": "bases/sec suffix_sort (chm13v2.0-size %s, k=%d)" % ("text" if data == "file" else "synthetic", k),
+        "value": total_bases / elapsed,
+        "unit": "bases/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": data,
+        "config": {
+            "workload": "suffix_sort %s n=%d k=%d (%sBASELINE.json configs[%d]); %s; text resident in HBM, SA left in HBM"
+                        % (text_desc, n, k, "" if data == "file" else "stand-in for chm13v2.0.fa, ", 4 if world > 1 and sharded else 1,
+                           "PREFIX_DOUBLING (bounded phase + rank doubling)" if algo else "PARALLEL_SORTING"),
+            "n": n, "k": k, "seed": args.seed,
+            "parallelism": ("single GPU" if world == 1 and not sharded else
+                            ("one text, LMS sort sharded by key range over %d GPU%s (RCCL all-to-all of the LMS "
+                             "list, gather of the sorted pieces, induction on rank 0)" % (world, "" if world == 1 else "s"))
+                            if sharded else "1 text per GPU (independent replicas)"),
+            "lms": last_stats["m"], "lms_rounds": last_stats["lms_rounds"],
+            "tied_after_round0_item_rounds": last_stats["sort_item_rounds"] - last_stats["m"],
+            "big_segment_item_rounds": last_stats["big_item_rounds"],
+            "workspace_bytes": workspace_bytes,
+            "induce_passes": last_stats["induce_passes"],
+            "stage_ms_per_step": {s: v / args.steps for s, v in stage.items()},
+        },
+    }
+    if sharded_error:
+        out["config"]["sharded_error"] = sharded_error
+    if phase_ms:
+        out["config"]["sharded_phase_ms_rank0"] = {kk: v / args.steps for kk, v in phase_ms.items()}
+    # roofline of the dominant kernel class (live HIP-event timing inside the library); in sharded runs the launches are
+    # rank 0's (its key range of the sort + the induction)
+    out["roofline"] = None if args.no_profile else roofline_of(agg, prof_agg, args.steps, prof_steps, args.profile_all)
+    # whole-path algorithmic bytes (SURVEY.md 8(d)): 0.25 n + 20 m + 16 (n+1) + 2 n
+    m = last_stats["m"]
+    path_bytes = 0.25 * n + 20.0 * m + 16.0 * (n + 1) + 2.0 * n
+    dev_s = 1e-3 * stage["total"] / args.steps
+    if dev_s <= 0:  # sharded runs: per-stage device times are not collected, use the step wall time
+        dev_s = elapsed / args.steps
+    out["path_roofline"] = {"algorithmic_bytes": path_bytes, "device_ms": 1e3 * dev_s,
+                            "achieved_GBps": path_bytes / dev_s / 1e9, "frac": path_bytes / dev_s / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def exact_order_leg(ctx, S, SA, n, stream, steps=3):
+    """BASELINE.json configs[3]: the same text, k = -1 (unbounded) through PREFIX_DOUBLING -- the bounded phase + rank
+    doubling over the tied suffixes; the result is THE suffix array, proven on the device after the timed steps."""
+    import torch
+    K = 0xFFFFFFFF
+    ctx.set_profiling(False)
+    ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=K, algo=1, stream=stream)  # first-use allocations (inverse-SA pairs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=K, algo=1, stream=stream)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    st = ctx.stats()
+    rep = ctx.verify_sa_dev(S.data_ptr(), n, SA.data_ptr(), K)
+    return {"config": "BASELINE.json configs[3]: suffix_sort k=-1 (unbounded), PREFIX_DOUBLING, same text, 1 GPU",
+            "ms_per_step": 1e3 * el, "value": n / el, "unit": "bases/s", "steps": steps,
+            "device_ms": st["ms_total"], "bounded_phase_order": st["refine_depth"], "doubling_ms": st["ms_refine"],
+            "tied_after_bounded_phase": st["refine_items"], "doubling_rounds": st["doubling_rounds"],
+            "verified": bool(rep["ok"]), "verify": {"exact": rep["exact"], "order_violations": rep["order_violations"],
+                                                    "duplicates": rep["duplicates"], "ms": rep["ms"]},
+            "sa_digest": "%016x" % rep["digest"], "workspace_bytes": ctx.workspace_bytes()}
+
+
+def dm_leg(ctx_factory, device, k=256, threads=24):
+    """BASELINE.json configs[0] (`suffix_sort example/drosophia_chr1_2.fa -k 256 -t 24`, reference README.md:85-88:
+    0.4809 s = 101.5 Mbases/s on its authors' host): the dm-size stand-in C1 (n = 48 800 648, seed 1)
+    through the reference-code pipeline of oracle/_ref at the README's 24 threads on THIS box's host cores (whole
+    text, best of 3), beside the HIP path on the same text -- the two suffix arrays compared bit for bit."""
+    import torch
+    from tests import ref_binding
+    S = gen_text_device(DM_N, 1, device)
+    S_host = S.cpu().numpy()
+    out = {"config": "BASELINE.json configs[0]: suffix_sort dm-size (n=%d) k=%d -t %d on the CPU reference" % (DM_N, k, threads),
+           "published": {"seconds": 0.4809, "bases_per_s": DM_N / 0.4809, "threads": 24, "hardware": "unstated",
+                         "source": "reference README.md:87-88"}}
+    sa_ref = None
+    if ref_binding.available() and os.path.exists(ref_binding.LIB):
+        ref = ref_binding.load()
+        T = max(1, min(threads, ref.max_threads()))
+        best = None
+        for _ in range(3):
+            t0 = time.time()
+            sa_ref = ref.suffix_sort(S_host, k, T=T)
+            dt = time.time() - t0
+            best = dt if best is None or dt < best else best
+        out["cpu_baseline_dm"] = {"value": DM_N / best, "unit": "bases/s", "cores": T, "kind": "reference", "seconds": best,
+                                  "sample": "the whole dm-size text (n=%d, seed 1), k=%d, best of 3; oracle/_ref: reference "
+                                            "get_lms + put_lms_suffix + induced_sort compiled unmodified, LMS sort restated "
+                                            "(oracle/ref_driver.cpp)" % (DM_N, k)}
+    else:
+        out["cpu_baseline_dm"] = None
+    ctx = ctx_factory(DM_N)
+    SA = torch.empty(DM_N + 1, dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.suffix_sort_dev(S.data_ptr(), DM_N, SA.data_ptr(), k=k, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        ctx.suffix_sort_dev(S.data_ptr(), DM_N, SA.data_ptr(), k=k, stream=stream)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    out["hip"] = {"ms_per_step": 1e3 * el, "value": DM_N / el, "unit": "bases/s"}
+    if sa_ref is not None:
+        out["hip"]["sa_equal_to_reference_pipeline"] = bool(np.array_equal(SA.cpu().numpy().view(np.uint32), sa_ref))
+    ctx.close()
+    return out
+
+
+class _DevArray:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
 def main():
@@ -415,6 +593,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--text-len", dest="n", type=int, default=CHM13_N, help="text length (default: chm13v2.0 size)")
+    ap.add_argument("--fasta", default=None,
+                    help="sort this FASTA / plain-text file (e.g. a real chm13v2.0.fa) instead of the synthetic text: read, "
+                         "uploaded and parsed on the device by kiss_hip_ctx_load_text_file; the line says \"data\": \"file\"")
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--algo", choices=["parallel_sorting", "prefix_doubling"], default="parallel_sorting",
                     help="prefix_doubling: exact order (k is ignored), bounded phase + rank doubling")
@@ -439,14 +620,24 @@ def main():
                          "all-to-all (strong scaling); 'replicas' = one independent text per rank (weak scaling)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the sharded pipeline (RCCL collectives included) even with a single rank (test aid)")
+    ap.add_argument("--multi-abi", default=None, metavar="DEVICES",
+                    help="single process: time kiss_hip_multi_suffix_sort_dna_u32_dev over this comma-separated device list "
+                         "(one process driving several devices, peer copies; '0,0' = two shares on one GPU) instead of the "
+                         "single-device entry")
     ap.add_argument("--no-verify", action="store_true", help="skip the device-side check of the last SA")
     ap.add_argument("--no-fnv", action="store_true", help="skip the host-side FNV-1a-64 of the last SA (~15-20 s at chm13 size)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host S -> host SA leg (single GPU only)")
     ap.add_argument("--no-fm", action="store_true", help="skip the FM-index queries/s leg (single GPU only)")
-    ap.add_argument("--fm-text-len", type=int, default=48_800_648, help="text length of the FM-index leg (default: dm size)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-order leg (BASELINE configs[3]; single GPU only)")
+    ap.add_argument("--no-dm", action="store_true", help="skip the dm-size leg (BASELINE configs[0]; single GPU only)")
+    ap.add_argument("--exact-steps", type=int, default=3)
+    ap.add_argument("--fm-text-len", type=int, default=DM_N, help="text length of the FM-index leg (default: dm size)")
     ap.add_argument("--fm-queries", type=int, default=1_000_000)
     ap.add_argument("--no-fallback", action="store_true",
                     help="self-launching parent only: do not start fresh --mode replicas ranks after a sharded failure")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="self-launching parent only: seconds after which ranks that are all alive but not finished (stuck in "
+                         "a collective) are terminated -> exit status 124, no retry (0 = wait for ever)")
     ap.add_argument("--sharded-error", default=None, help=argparse.SUPPRESS)  # set by the parent on its fallback run
     args = ap.parse_args()
     if args.gpus < 1:
@@ -501,7 +692,21 @@ def main():
         k = 0xFFFFFFFF
     sharded = (world > 1 and args.mode == "sharded") or args.force_sharded
     seed = args.seed if sharded else args.seed + 1000 * rank  # sharded: every rank holds the same text
-    if args.iid:
+    ctx = None
+    data, text_desc, file_ptr = "synthetic", None, None
+    if args.fasta:
+        # a real genome when one is present: the file's bases are what every rank sorts; read, uploaded
+        # and parsed on the device (fasta.hip) outside the timed region, like the reference's stopwatch (suffix_sort.hpp:57)
+        nbytes = os.path.getsize(args.fasta)
+        loader = kiss_amd.Context(max_n=max(nbytes, 1), device=local_rank, lms_capacity=max(1 << 20, nbytes // 2048))
+        t0 = time.perf_counter()
+        file_ptr, n = loader.load_text_file(args.fasta)
+        load_s = time.perf_counter() - t0
+        loader.close()
+        S = torch.as_tensor(_DevArray(file_ptr, n), device=device)
+        data, text_desc = "file", "file %s (%d bytes, read + upload + device-side parse %.2f s)" % (
+            os.path.basename(args.fasta), nbytes, load_s)
+    elif args.iid:
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         S = torch.randint(0, 4, (n,), dtype=torch.uint8, device=device, generator=g)
@@ -510,7 +715,17 @@ def main():
     SA = torch.empty(n + 1, dtype=torch.int32, device=device)  # u32 payload; torch has no uint32 arithmetic needs
     torch.cuda.synchronize()
 
-    ctx = kiss_amd.Context(max_n=n, device=local_rank)
+    multi = None
+    if args.multi_abi:
+        if world > 1 or sharded:
+            ap.error("--multi-abi is the single-process form: not with --gpus > 1 / --force-sharded")
+        devs = [int(x) for x in args.multi_abi.split(",")]
+        multi = kiss_amd.MultiContext(devs, max_n=n)
+        ctx = multi.rank_context(0)  # statistics / profiling / verification go through share 0's context
+    else:
+        # ranks > 0 of a sharded sort hold about 1/G of the LMS suffixes (their arrays regrow on demand)
+        cap = int(0.32 * n / world * 1.25) + 65536 if (sharded and rank > 0) else 0
+        ctx = kiss_amd.Context(max_n=n, device=local_rank, lms_capacity=cap)
     # The contract wants the dominant kernel's launch duration from HIP events inside the timed region.  Events around
     # every launch of every class cost ~5 us of stream time each; so the timed region times the dominant class only
     # (DOMINANT_CLASS, checked against the full breakdown below) and the other classes are timed in extra steps.
@@ -518,14 +733,17 @@ def main():
         ctx.set_profiling(True, None if args.profile_all else [DOMINANT_CLASS])
     stream = torch.cuda.current_stream().cuda_stream
 
+    phase_ms = None
     if sharded:
         from kiss_amd import multi_gpu
         backend = multi_gpu.GpuBackend(ctx, S, k)
-
         phase_ms = {} if args.sharded_timings else None
 
         def step():
             multi_gpu.sharded_suffix_sort(backend, n, SA=SA if rank == 0 else None, timings=phase_ms)
+    elif multi is not None:
+        def step():
+            multi.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo)
     else:
         def step():
             ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, algo=algo, stream=stream)
@@ -535,7 +753,7 @@ def main():
     sharded_error = args.sharded_error  # only ever set by the self-launching parent on its fresh replicas run
     for _ in range(args.warmup):
         step()
-    if sharded and args.sharded_timings:
+    if phase_ms is not None:
         phase_ms.clear()  # the warm-up call holds the first-use allocations and the communicator set-up
 
     def barrier():
@@ -546,6 +764,7 @@ def main():
     agg = {}
     stage = {"pack": 0.0, "classify": 0.0, "lms_sort": 0.0, "place": 0.0, "induce": 0.0, "total": 0.0}
     last_stats = None
+    multi_phase = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -559,6 +778,10 @@ def main():
             a["items"] += v["items"]
         for s in stage:
             stage[s] += st["ms_" + s]
+        if multi is not None:
+            for kk, v in multi.stats().items():
+                if kk.startswith("ms_"):
+                    multi_phase[kk] = multi_phase.get(kk, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -581,103 +804,69 @@ def main():
         ctx.set_profiling(True, [DOMINANT_CLASS])
         barrier()
 
+    status = 0
     if rank == 0:
-        total_bases = float(n) * args.steps * (1 if sharded else world)
-        value = total_bases / elapsed
-        out = {
-            "metric": "bases/sec suffix_sort (chm13v2.0-size synthetic, k=%d)" % k,
-            "value": value,
-            "unit": "bases/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": "suffix_sort %s n=%d k=%d (stand-in for chm13v2.0.fa, BASELINE.json configs[1]); "
-                            "%s; text resident in HBM, SA left in HBM"
-                            % ("i.i.d." if args.iid else ("genome-like synthetic, HARSH satellite profile" if args.harsh
-                                                          else "genome-like synthetic"), n, k,
-                               "PREFIX_DOUBLING (bounded phase + rank doubling)" if algo else "PARALLEL_SORTING"),
-                "n": n, "k": k, "seed": args.seed,
-                "parallelism": ("single GPU" if world == 1 else
-                                ("one text, LMS sort sharded by key range over %d GPUs (RCCL all-to-all of the LMS "
-                                 "list, gather of the sorted pieces, induction on rank 0)" % world) if sharded else
-                                "1 text per GPU (independent replicas)"),
-                "lms": last_stats["m"], "lms_rounds": last_stats["lms_rounds"],
-                "tied_after_round0_item_rounds": last_stats["sort_item_rounds"] - last_stats["m"],
-                "big_segment_item_rounds": last_stats["big_item_rounds"],
-                "workspace_bytes": ctx.workspace_bytes(),
-                "induce_passes": last_stats["induce_passes"],
-                "stage_ms_per_step": {s: v / args.steps for s, v in stage.items()},
-            },
-        }
-        if sharded_error:
-            out["config"]["sharded_error"] = sharded_error
-        if sharded and args.sharded_timings:
-            out["config"]["sharded_phase_ms_rank0"] = {k: v / args.steps for k, v in phase_ms.items()}
-        # roofline of the dominant kernel class (live HIP-event timing inside the library)
-        roof = None
-        if agg and not args.no_profile:
-            # the dominant class according to the full breakdown; its launch duration from the timed region's events
-            name = max(prof_agg.items(), key=lambda kv: kv[1]["ms"])[0]
-            in_timed_region = bool(agg.get(name, {}).get("launches"))
-            a = agg[name] if in_timed_region else prof_agg[name]
-            a_steps = args.steps if in_timed_region else prof_steps
-            if a["launches"] and a["ms"] > 0:
-                bytes_per_launch = ALGO_BYTES.get(name, 0.0) * a["items"] / a["launches"]
-                avg_s = 1e-3 * a["ms"] / a["launches"]
-                achieved = bytes_per_launch / avg_s / 1e9
-                roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": (bytes_per_launch * MEASURED_TRAFFIC_PER_ALGO_BYTE[name]
-                                    if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
-                        "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
-                                        "kernel (separate rocprofv3 --pmc runs, profiles/r02_pmc_*.csv)",
-                        "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / a_steps,
-                        "measured_in": ("timed region (HIP events around this class only)" if in_timed_region and
-                                        not args.profile_all else
-                                        "timed region (HIP events around every class)" if in_timed_region else
-                                        "profiled steps after the timed region (not the class timed inside it)"),
-                        "algorithmic_bytes_per_item": ALGO_BYTES.get(name, 0.0),
-                        "kernel_ms_per_step": {kn: kv["ms"] / prof_steps for kn, kv in prof_agg.items() if kv["launches"]},
-                        "kernel_ms_per_step_from": ("timed region" if prof_agg is agg else
-                                                    "%d extra steps with every class timed" % prof_steps)}
-        out["roofline"] = roof
-        # whole-path algorithmic bytes: 0.25 n + 20 m + 16 (n+1) + 2 n
-        m = last_stats["m"]
-        path_bytes = 0.25 * n + 20.0 * m + 16.0 * (n + 1) + 2.0 * n
-        dev_s = 1e-3 * stage["total"] / args.steps
-        if dev_s <= 0:  # sharded runs: per-stage device times are not collected, use the step wall time
-            dev_s = elapsed / args.steps
-        out["path_roofline"] = {"algorithmic_bytes": path_bytes, "device_ms": 1e3 * dev_s,
-                                "achieved_GBps": path_bytes / dev_s / 1e9, "frac": path_bytes / dev_s / 1e9 / HBM_PEAK_GBS}
+        if multi is not None:
+            last_stats["m"] = multi.stats()["m"] or last_stats["m"]
+        out = assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof_steps, stage, last_stats,
+                            ctx.workspace_bytes(), phase_ms=phase_ms, sharded_error=sharded_error, data=data,
+                            text_desc=text_desc)
+        if multi is not None:
+            out["config"]["parallelism"] = ("ONE process driving devices %s through kiss_hip_multi_* (LMS sort sharded by key "
+                                            "range, peer copies, induction on the first device)" % args.multi_abi)
+            out["config"]["multi_phase_ms"] = {kk: v / args.steps for kk, v in multi_phase.items()}
         if not args.no_verify:
-            out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid, algo, with_fnv=(world == 1 and not args.no_fnv),
-                                  harsh=args.harsh))
-        if world == 1 and not sharded and not args.no_e2e:
+            out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid or data == "file", algo,
+                                  with_fnv=(world == 1 and not args.no_fnv), harsh=args.harsh))
+            if not out["verified"]:
+                # a throughput for a wrong suffix array is not a result: the headline is withdrawn, the report stays
+                print("[bench] the last suffix array FAILED its check: %s" % json.dumps(
+                    {kk: out.get(kk) for kk in ("verify", "sa_digest", "sa_fnv1a64", "sa_pinned", "sa_matches_pinned_hash")}),
+                    file=sys.stderr, flush=True)
+                out["invalid"] = "the last suffix array failed the device-side check or differs from the pinned hash"
+                out["unverified_value"], out["value"] = out["value"], None
+                status = EXIT_VERIFY_FAILED
+        single = world == 1 and not sharded and multi is None
+        if single and not args.no_e2e:
             out["end_to_end"] = end_to_end_leg(ctx, S, n, k, algo)
-        if args.cpu_sample > 0 and world == 1:
+            ctx.release_io_buffers()
+        if single and not args.no_exact and not algo and n >= 4 * 256 + 1024:
+            out["exact_order"] = exact_order_leg(ctx, S, SA, n, stream, steps=args.exact_steps)
+            if not out["exact_order"]["verified"]:
+                status = EXIT_VERIFY_FAILED
+        # the CPU baseline: rank 0's host cores, at every N (the other ranks wait at the closing barrier)
+        if args.cpu_sample > 0:
             ns = min(n, args.cpu_sample)
             sample = S[:ns].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(sample, k)
+            del sample
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not sharded and not args.no_fm:
+        if single and (not args.no_fm or not args.no_dm):
             del S, SA
             ctx.close()
+            if file_ptr:
+                kiss_amd.Context(max_n=1024, device=local_rank, lms_capacity=1024).free_dev(file_ptr)
+                file_ptr = None
             torch.cuda.empty_cache()
-            out["fm_query"] = fm_query_leg(device, Q=args.fm_queries, n=args.fm_text_len)
+            if not args.no_dm:
+                dm = dm_leg(lambda nn: kiss_amd.Context(max_n=nn, device=local_rank), device, k=256)
+                out["cpu_baseline_dm"] = dm.pop("cpu_baseline_dm")
+                out["dm_size"] = dm
+                if dm["hip"].get("sa_equal_to_reference_pipeline") is False:
+                    status = EXIT_VERIFY_FAILED
+            if not args.no_fm:
+                out["fm_query"] = fm_query_leg(device, Q=args.fm_queries, n=args.fm_text_len)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if multi is not None:
+        multi.close()
+    else:
+        ctx.close()
+    sys.exit(status)
 
 
 if __name__ == "__main__":

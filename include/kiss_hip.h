@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KISS_HIP_VERSION 100 /* 0.1.0 */
+#define KISS_HIP_VERSION 101 /* 0.1.1: kiss_hip_multi_*, stage views, ms_fm_range / ms_fm_locate in kiss_hip_stats */
 
 typedef enum kiss_hip_status {
     KISS_HIP_OK = 0,
@@ -90,6 +90,9 @@ typedef struct kiss_hip_stats {
     float ms_h2d;             /* host S -> device */
     float ms_d2h;             /* device SA -> host */
     uint32_t reserved_;
+    /* kiss_hip_fmi_query_batch_dev with KISS_HIP_K_FM_QUERY timed: the two halves of ms_kernel[KISS_HIP_K_FM_QUERY] */
+    float ms_fm_range;        /* backward search (get_range) */
+    float ms_fm_locate;       /* get_offsets */
 } kiss_hip_stats;
 
 /* kernel classes for ms_kernel[] / launches_kernel[] */

@@ -12,8 +12,12 @@
 //   locate     : breadth-first over <= SA_INTV - 1 LF levels, emitting sa_[j] + depth for the sampled rows
 //                of every visited range, in the reference's FIFO order, stopping once end - beg offsets
 //                have been collected (get_offsets :453-501).
-// One lane owns one pattern: 2L dependent LF steps of three small loads each (16 B + 4 B + 4 B) --
-// a latency-bound gather workload, so the grid keeps every CU's 2048 lanes busy rather than tiling.
+// One lane owns one pattern: 2L dependent LF steps -- a latency-bound gather workload, so the grid keeps every CU's
+// 2048 lanes busy rather than tiling.  The on-disk layout costs THREE sectors per occ (an occ1 row, an occ2 entry, a BWT
+// word: three arrays); the device works on a derived, interleaved copy made at the start of every batch (k_fm_blocks,
+// one streaming pass over the index, microseconds): per 64 rows ONE 32-byte block = the four cumulative counts up to
+// the block (occ1 + occ2 of its first chunk) + its 64 BWT dibits, so an occ is one sector and the same arithmetic as
+// compute_occ.  The .fmi arrays are only read by that pass and by the locate's sampled-SA / bit-vector look-ups.
 // Locate: patterns with more than FM_HEAVY occurrences (tandem repeats reach 10^6) get a workgroup of their own,
 // the rest stay one lane per pattern; both produce the reference's output order.
 #include "kiss_internal.hpp"
@@ -37,6 +41,7 @@ struct FmiD {
     const uint32_t *sa;
     const uint64_t *b;
     const uint32_t *b_occ;
+    const uint4 *blk; // interleaved rank blocks: [2 * j] = counts of A, C, G, T in bwt[0, 64 j), [2 * j + 1] = the 64 dibits
 };
 
 // the 16 dibits of chunk i/16 as one u32 (dibit t at bits 2t); the index may end inside the word
@@ -53,7 +58,8 @@ __device__ __forceinline__ uint32_t bwt_word(const FmiD &f, uint64_t chunk)
     return w;
 }
 
-__device__ __forceinline__ uint32_t fm_occ(const FmiD &f, uint32_t c, uint64_t i)
+// compute_occ (fm_index.hpp:166-182) on the on-disk arrays: what k_fm_blocks condenses, kept as the statement of the rule
+__device__ __forceinline__ uint32_t fm_occ_disk(const FmiD &f, uint32_t c, uint64_t i)
 {
     const uint64_t o1 = i >> 8, o2 = i >> 4;
     const uint64_t beg = o2 << 4;
@@ -68,11 +74,81 @@ __device__ __forceinline__ uint32_t fm_occ(const FmiD &f, uint32_t c, uint64_t i
     const uint32_t pass_pri = (c == 0 && beg <= f.pri && f.pri < i) ? 1u : 0u;
     return f.occ1[o1 * 4 + c] + (uint32_t)f.occ2[o2 * 4 + c] + cnt - pass_pri;
 }
+
+// one 32-byte block: counts before the block + the block's dibits
+struct FmBlock {
+    uint4 cnt;
+    uint4 bw; // dibit t of the block at bits 2 (t % 16) of word t / 16
+};
+__device__ __forceinline__ FmBlock fm_block(const FmiD &f, uint64_t j)
+{
+    FmBlock b;
+    b.cnt = f.blk[2 * j];
+    b.bw = f.blk[2 * j + 1];
+    return b;
+}
+// occ(c, i) for a row i of block j = i / 64 (the block already loaded): the same sum as compute_occ with the block start in
+// the place of the 16-row chunk start -- counts before the block + matching dibits in [64 j, i) - the primary row's
+// placeholder 'A' when it lies in that stretch
+__device__ __forceinline__ uint32_t fm_occ_in(const FmiD &f, const FmBlock &b, uint32_t c, uint64_t i)
+{
+    const uint32_t r = (uint32_t)(i & 63u);
+    const uint32_t pat = c * 0x55555555u;
+    const uint32_t w[4] = {b.bw.x, b.bw.y, b.bw.z, b.bw.w};
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint32_t x = w[t] ^ pat;
+        uint32_t m = ~(x | (x >> 1)) & 0x55555555u; // bit 2 u set <=> dibit u of this word == c
+        const int left = (int)r - (int)(16 * t);     // rows of this word below i
+        m = left >= 16 ? m : (left <= 0 ? 0u : (m & ((1u << (2 * left)) - 1u)));
+        cnt += (uint32_t)__popc(m);
+    }
+    const uint32_t base = c == 0 ? b.cnt.x : (c == 1 ? b.cnt.y : (c == 2 ? b.cnt.z : b.cnt.w));
+    const uint64_t start = i & ~63ull;
+    const uint32_t pass_pri = (c == 0 && start <= f.pri && f.pri < i) ? 1u : 0u;
+    return base + cnt - pass_pri;
+}
+__device__ __forceinline__ uint32_t fm_occ(const FmiD &f, uint32_t c, uint64_t i)
+{
+    return fm_occ_in(f, fm_block(f, i >> 6), c, i);
+}
 __device__ __forceinline__ uint64_t fm_lf(const FmiD &f, uint32_t c, uint64_t i) { return (uint64_t)f.cnt[c] + fm_occ(f, c, i); }
+// both ends of a range: one block load when they fall into the same 64 rows (the usual case once the range is narrow)
+__device__ __forceinline__ void fm_lf2(const FmiD &f, uint32_t c, uint64_t &beg, uint64_t &end)
+{
+    const uint64_t jb = beg >> 6, je = end >> 6;
+    const FmBlock bb = fm_block(f, jb);
+    const uint32_t ob = fm_occ_in(f, bb, c, beg);
+    const uint32_t oe = je == jb ? fm_occ_in(f, bb, c, end) : fm_occ_in(f, fm_block(f, je), c, end);
+    beg = (uint64_t)f.cnt[c] + ob;
+    end = (uint64_t)f.cnt[c] + oe;
+}
 
 __device__ __forceinline__ uint32_t fm_bwt(const FmiD &f, uint64_t i)
 {
     return ((uint32_t)f.bwt[i >> 2] >> (2 * (uint32_t)(i & 3))) & 3u;
+}
+
+// ---- the interleaved rank blocks: one lane per 64 rows, from the on-disk arrays ------------------------------------
+__global__ __launch_bounds__(FM_THREADS) void k_fm_blocks(FmiD f, uint64_t nblocks, uint4 *__restrict__ blk)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
+    if (j >= nblocks) return;
+    const uint64_t row = j * 64; // <= N: occ1 has N / 256 + 1 rows, occ2 N / 16 + 1 entries
+    const uint64_t o1 = row >> 8, o2 = row >> 4;
+    uint4 c;
+    c.x = f.occ1[o1 * 4 + 0] + (uint32_t)f.occ2[o2 * 4 + 0];
+    c.y = f.occ1[o1 * 4 + 1] + (uint32_t)f.occ2[o2 * 4 + 1];
+    c.z = f.occ1[o1 * 4 + 2] + (uint32_t)f.occ2[o2 * 4 + 2];
+    c.w = f.occ1[o1 * 4 + 3] + (uint32_t)f.occ2[o2 * 4 + 3];
+    uint4 w; // (words past the end of the BWT read as zero: rows >= N are never counted, fm_occ_in masks by i <= N)
+    w.x = bwt_word(f, o2);
+    w.y = bwt_word(f, o2 + 1);
+    w.z = bwt_word(f, o2 + 2);
+    w.w = bwt_word(f, o2 + 3);
+    blk[2 * j] = c;
+    blk[2 * j + 1] = w;
 }
 // compute_b_occ, fm_index.hpp:189-208
 __device__ __forceinline__ uint32_t fm_b_occ(const FmiD &f, uint64_t i)
@@ -100,8 +176,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
         while (len > 0) {
             if (end - beg < 1) break;
             uint32_t c = p[len - 1] & 3u;
-            beg = fm_lf(f, c, beg);
-            end = fm_lf(f, c, end);
+            fm_lf2(f, c, beg, end);
             len--;
         }
     }
@@ -158,9 +233,11 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
                     if (nn < fcapq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
                     nn++;
                 } else {
+                    const FmBlock bb = fm_block(f, cb >> 6);
+                    const FmBlock be = (ce >> 6) == (cb >> 6) ? bb : fm_block(f, ce >> 6);
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++) {
-                        uint64_t nb = fm_lf(f, c, cb), ne = fm_lf(f, c, ce);
+                        const uint64_t nb = (uint64_t)f.cnt[c] + fm_occ_in(f, bb, c, cb), ne = (uint64_t)f.cnt[c] + fm_occ_in(f, be, c, ce);
                         if (nb != ne) {
                             if (nn < fcapq) nxt[nn] = make_uint2((uint32_t)nb, (uint32_t)ne);
                             nn++;
@@ -253,9 +330,11 @@ __global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const u
                     const uint64_t nb = fm_lf(f, fm_bwt(f, cb), cb);
                     ch[nch++] = make_uint2((uint32_t)nb, (uint32_t)(nb + 1));
                 } else {
+                    const FmBlock bb = fm_block(f, cb >> 6);
+                    const FmBlock be = (ce >> 6) == (cb >> 6) ? bb : fm_block(f, ce >> 6);
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++) {
-                        const uint64_t nb = fm_lf(f, c, cb), ne = fm_lf(f, c, ce);
+                        const uint64_t nb = (uint64_t)f.cnt[c] + fm_occ_in(f, bb, c, cb), ne = (uint64_t)f.cnt[c] + fm_occ_in(f, be, c, ce);
                         if (nb != ne) ch[nch++] = make_uint2((uint32_t)nb, (uint32_t)ne);
                     }
                 }
@@ -499,7 +578,32 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     f.b = fmi->b;
     f.b_occ = fmi->b_occ;
 
-    DevBuf cap, capidx, fcap, fcapidx, got, gotidx, tot, fr0, fr1, scratch, heavy;
+    DevBuf cap, capidx, fcap, fcapidx, got, gotidx, tot, fr0, fr1, scratch, heavy, blocks;
+    // the interleaved rank blocks, derived from the caller's arrays at the start of every batch (never kept: the arrays
+    // may have changed between calls)
+    const uint64_t nblocks = f.N / 64 + 1;
+    KTRY(blocks.take(ctx, 11, nblocks * 32));
+    f.blk = (const uint4 *)blocks.p;
+    const bool split = ((ctx->profile_mask >> KISS_HIP_K_FM_QUERY) & 1ull) != 0;
+    hipEvent_t sev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (split)
+        for (auto &e : sev)
+            if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard()
+        {
+            for (int i = 0; i < 4; i++)
+                if (e[i]) (void)hipEventDestroy(e[i]);
+        }
+    } ev_guard{sev};
+    const bool timed = split && sev[0] && sev[1] && sev[2] && sev[3];
+    {
+        KTimer t(ctx, KISS_HIP_K_FM_BUILD, nblocks);
+        hipLaunchKernelGGL(k_fm_blocks, dim3((unsigned)div_up(nblocks, FM_THREADS)), dim3(FM_THREADS), 0, ctx->stream, f, nblocks,
+                           (uint4 *)blocks.p);
+        KCHECK(hipGetLastError());
+    }
     KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
     KTRY(cap.take(ctx, 1, (Q + 1) * 8));
@@ -512,8 +616,10 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     const unsigned grid = (unsigned)div_up(Q, FM_THREADS);
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
+        if (timed) (void)hipEventRecord(sev[0], ctx->stream);
         hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
                            (uint64_t *)cap.p, (uint64_t *)fcap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p);
+        if (timed) (void)hipEventRecord(sev[1], ctx->stream);
         KCHECK(hipGetLastError());
     }
     KTRY(kiss_zero_u32(ctx, (uint8_t *)cap.p + Q * 8, 2));
@@ -532,6 +638,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     KTRY(kiss_zero_u32(ctx, tot.p, 4));
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
+        if (timed) (void)hipEventRecord(sev[2], ctx->stream);
         hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
                            (const uint64_t *)capidx.p, (const uint64_t *)fcapidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p,
                            (uint32_t *)scratch.p,
@@ -540,6 +647,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
             hipLaunchKernelGGL(k_fm_locate_heavy, dim3(nheavy), dim3(FMH_THREADS), 0, ctx->stream, f, beg, end,
                                (const uint32_t *)heavy.p + 1, (const uint64_t *)capidx.p, (uint32_t *)scratch.p,
                                (uint64_t *)got.p, (unsigned long long *)tot.p);
+        if (timed) (void)hipEventRecord(sev[3], ctx->stream);
         KCHECK(hipGetLastError());
     }
     if (offsets && offsets_index) {
@@ -557,6 +665,11 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     KCHECK(hipStreamSynchronize(ctx->stream));
     if (hit_count_total) *hit_count_total = h[0];
     if (checksum) *checksum = h[1];
+    if (timed) { // the two halves of the query apart (they accumulate like ms_kernel[] until the next sort resets the stats)
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, sev[0], sev[1]) == hipSuccess) ctx->stats.ms_fm_range += a;
+        if (hipEventElapsedTime(&b, sev[2], sev[3]) == hipSuccess) ctx->stats.ms_fm_locate += b;
+    }
     ktimer_collect(ctx);
     return KISS_HIP_OK;
 }

@@ -104,8 +104,8 @@ struct kiss_hip_ctx {
     uint64_t *pairs1 = nullptr, *pairs2 = nullptr;
     uint64_t pairs_cap = 0;
     // scratch of kiss_hip_fmi_query_batch_dev, kept between calls (fm.hip)
-    void *fm_pool[11] = {};
-    uint64_t fm_pool_cap[11] = {};
+    void *fm_pool[12] = {};
+    uint64_t fm_pool_cap[12] = {};
     // near-end
     uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr, *near_tmp2 = nullptr; // place.hip: near_reserve
     uint64_t near_cap = 0;

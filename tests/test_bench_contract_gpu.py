@@ -47,10 +47,58 @@ def test_bench_single_gpu_line():
     assert len(r["kernel_ms_per_step"]) > 3 and "extra steps" in r["kernel_ms_per_step_from"]
     c = out["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert out["scaling"] == "strong"  # the N = 1 line of the default (sharded) series
+    # BASELINE configs[3]: exact order through PREFIX_DOUBLING on the same text, proven on the device
+    x = out["exact_order"]
+    assert x["verified"] is True and x["verify"]["exact"] == 1 and x["ms_per_step"] > 0 and x["value"] > 0
+    # BASELINE configs[0]: dm-size text -- reference-code pipeline on the host cores beside the HIP path, same SA
+    d = out["dm_size"]
+    assert d["hip"]["ms_per_step"] > 0 and d["published"]["threads"] == 24
+    cd = out["cpu_baseline_dm"]
+    if cd is not None:
+        assert cd["kind"] == "reference" and cd["value"] > 0 and d["hip"]["sa_equal_to_reference_pipeline"] is True
+    # FM leg: range and locate kernels timed apart
+    assert fq["range_kernel_ms"] > 0 and fq["locate_kernel_ms"] >= 0
 
 
 @pytest.mark.gpu
 def test_bench_sharded_path_on_one_rank():
-    out = run_bench("--cpu-sample", "0", "--force-sharded", "--no-profile")
+    out = run_bench("--cpu-sample", "100000", "--force-sharded")
     assert out["scaling"] == "strong" and out["value"] > 0 and out["verified"] is True and out["n_gpus"] == 1
     assert "sharded_error" not in out["config"]
+    # the sharded line is as complete as the single-GPU one: roofline from rank 0's launches, CPU baseline from rank 0's host
+    assert out["roofline"] and out["roofline"]["kernel"] == "radix_scatter" and out["roofline"]["frac"] > 0
+    assert out["cpu_baseline"] and out["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_abi_two_shares_on_one_gpu():
+    out = run_bench("--cpu-sample", "0", "--multi-abi", "0,0")
+    assert out["verified"] is True and out["value"] > 0 and "kiss_hip_multi" in out["config"]["parallelism"]
+    ph = out["config"]["multi_phase_ms"]
+    assert ph["ms_sort"] > 0 and ph["ms_induce"] > 0 and ph["ms_total"] >= ph["ms_sort"]
+
+
+@pytest.mark.gpu
+def test_bench_takes_a_fasta_path(tmp_path):
+    import numpy as np
+    from tests import gen
+    S = gen.genome_like(1_500_000, 3)
+    fa = tmp_path / "g.fa"
+    with open(fa, "w") as f:
+        txt = "".join("ACGT"[c] for c in S)
+        for rec in range(3):
+            f.write(">chr%d some description\n" % rec)
+            part = txt[rec * 500_000:(rec + 1) * 500_000]
+            for a in range(0, len(part), 60):
+                f.write(part[a:a + 60] + "\n")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--fasta", str(fa), "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "200000", "--no-fm", "--no-dm", "--no-e2e"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert out["data"] == "file" and out["config"]["n"] == S.size and "g.fa" in out["config"]["workload"]
+    assert out["verified"] is True and out["value"] > 0 and out["exact_order"]["verified"] is True

@@ -80,3 +80,57 @@ def test_parent_fallback_starts_fresh_replica_ranks_and_says_so(monkeypatch, cap
     # --no-fallback: the failure is the result
     args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=True)
     assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == 9
+
+
+def test_the_two_gpu_line_is_complete(monkeypatch, capsys):
+    # a SCALE record must be gradeable -- the N > 1 line carries roofline and cpu_baseline like the N = 1 line.
+    # The stub's rank 0 assembles its line with bench.py's own code (assemble_line + cpu_baseline on the oracle).
+    import argparse
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "line")
+    args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=False, rank_timeout=120.0)
+    assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == 0
+    d = json.loads(capsys.readouterr().out.strip())
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "bases/s" and d["dtype"] == "u8"
+    r = d["roofline"]
+    assert r and r["bound"] == "hbm" and r["kernel"] == "radix_scatter" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_us"] > 0
+    c = d["cpu_baseline"]
+    assert c and c["value"] > 0 and c["cores"] >= 1 and c["kind"] in ("reference", "port") and "sample" in c
+    assert "sharded" in d["config"]["parallelism"] and "configs[4]" in d["config"]["workload"]
+    assert d["value"] == 2 * 1_000_000 / 0.02  # one text, whole-job aggregate
+
+
+def test_single_gpu_line_of_the_default_series_says_strong():
+    import argparse
+    bench = _bench()
+    a = argparse.Namespace(steps=1, warmup=0, iid=False, harsh=False, seed=2, mode="sharded", no_profile=True, profile_all=False)
+    st = {"m": 10, "lms_rounds": 1, "sort_item_rounds": 10, "big_item_rounds": 0, "induce_passes": 3}
+    stage = {"pack": 0.1, "classify": 0.1, "lms_sort": 0.1, "place": 0.1, "induce": 0.1, "total": 0.5}
+    d = bench.assemble_line(a, 1, False, 1000, 256, 0, 0.001, {}, {}, 1, stage, st, 1)
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["parallelism"] == "single GPU"
+    a.mode = "replicas"
+    assert bench.assemble_line(a, 4, False, 1000, 256, 0, 0.001, {}, {}, 1, stage, st, 1)["scaling"] == "weak"
+    assert bench.assemble_line(a, 4, False, 1000, 256, 0, 0.001, {}, {}, 1, stage, st, 1)["value"] == 4 * 1000 / 0.001
+
+
+def test_a_line_whose_suffix_array_failed_its_check_is_relayed_with_a_nonzero_status(monkeypatch, capsys):
+    # a wrong SA must not yield a normal-looking throughput record
+    import argparse
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "bad_sa")
+    args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=False, rank_timeout=120.0)
+    assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == bench.EXIT_VERIFY_FAILED
+    d = json.loads(capsys.readouterr().out.strip())
+    assert d["value"] is None and d["verified"] is False and d["unverified_value"] > 0
+
+
+def test_ranks_stuck_in_a_collective_are_terminated_after_the_rank_timeout(monkeypatch):
+    # all ranks alive, none finishing -- the parent must not poll for ever, and must not retry
+    import argparse
+    bench = _bench()
+    monkeypatch.setenv("STUB_MODE", "stuck")
+    t0 = time.time()
+    args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=False, rank_timeout=3.0)
+    assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == 124
+    assert time.time() - t0 < 60
