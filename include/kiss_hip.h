@@ -297,6 +297,8 @@ int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint
  * 32-bit payload, and its exclusive u32 scan, run on caller data in host memory (count <= ctx LMS capacity). */
 int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, uint64_t count, int key_lo_bit);
 int kiss_hip_debug_scan_u32(kiss_hip_ctx *ctx, uint32_t *data, uint64_t count);
+/* fault injection: from now on work-array allocations of this ctx above `bytes` fail with KISS_HIP_E_NOMEM (0 = off) */
+int kiss_hip_debug_fail_alloc_over(kiss_hip_ctx *ctx, uint64_t bytes);
 /* host only: the key-range rule of the multi-device sort (kiss_hip_multi_*) on a caller's histogram of `bins` entries:
  * groups - 1 splitters (group of a bin = number of splitters <= bin) and the resulting items per group */
 int kiss_hip_debug_splitters(const uint64_t *hist, uint64_t bins, int groups, uint32_t *splitters_out,

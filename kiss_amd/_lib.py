@@ -125,6 +125,8 @@ def load():
     lib.kiss_hip_suffix_sort_dna_u32_multi.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, vp, ip, ctypes.c_int]
     lib.kiss_hip_stage_view.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint64)]
     lib.kiss_hip_stage_reserve.argtypes = [vp, ctypes.c_uint64]
+    lib.kiss_hip_debug_fail_alloc_over.argtypes = [vp, ctypes.c_uint64]
+    lib.kiss_hip_debug_fail_alloc_over.restype = ctypes.c_int
     lib.kiss_hip_debug_splitters.argtypes = [vp, ctypes.c_uint64, ctypes.c_int, vp, vp]
     lib.kiss_hip_debug_splitters.restype = ctypes.c_int
     lib.kiss_hip_ctx_destroy.argtypes = [vp]
@@ -210,5 +212,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_ctx_create_sized", "kiss_hip_ctx_release_io_buffers", "kiss_hip_stage_view", "kiss_hip_stage_reserve",
     "kiss_hip_multi_create", "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32",
     "kiss_hip_multi_suffix_sort_dna_u32_dev", "kiss_hip_multi_get_stats", "kiss_hip_multi_ctx",
-    "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters",
+    "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters", "kiss_hip_debug_fail_alloc_over",
 ]

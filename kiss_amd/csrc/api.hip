@@ -99,8 +99,8 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
 {
     void *q = nullptr;
     uint64_t bytes = (count ? count : 1) * sizeof(T);
-    // fault-injection hook of tests/test_suffix_sort_gpu.py: work arrays above this many bytes "do not fit" (the
-    // environment is looked at once per ctx, kiss_hip_ctx_create_sized; 0 = no limit)
+    // fault-injection hook of tests/test_suffix_sort_gpu.py (kiss_hip_debug_fail_alloc_over): work arrays above this many
+    // bytes "do not fit"; 0 = no limit.  No environment look-up per allocation in the shipped path.
     hipError_t e = ctx->fail_alloc_over && bytes > ctx->fail_alloc_over ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError(); // (or the next launch check reports this failure as its own)
@@ -519,7 +519,6 @@ int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, ui
     ctx->device = device;
     ctx->max_n = max_n;
     ctx->m_cap0 = lms_capacity ? lms_capacity + 4096 : 0;
-    if (const char *cap = getenv("KISS_HIP_FAIL_ALLOC_OVER")) ctx->fail_alloc_over = strtoull(cap, nullptr, 10);
     int rc = KISS_HIP_OK;
     do {
         if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
@@ -685,6 +684,13 @@ int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, 
     ktimer_collect(ctx); // kernel-class times of this call show up in kiss_hip_get_stats (tools/radix_probe.py)
     KCHECK(hipMemcpy(keys, rb.key[res], count * 8, hipMemcpyDeviceToHost));
     KCHECK(hipMemcpy(pos, rb.pos[res], count * 4, hipMemcpyDeviceToHost));
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_debug_fail_alloc_over(kiss_hip_ctx *ctx, uint64_t bytes)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    ctx->fail_alloc_over = bytes;
     return KISS_HIP_OK;
 }
 

@@ -44,7 +44,7 @@ struct kiss_hip_ctx {
     hipStream_t stream = nullptr;  // stream of the current call
     uint64_t max_n = 0;
     uint64_t m_cap = 0;            // capacity of the per-LMS arrays (every LMS suffix of the text)
-    uint64_t fail_alloc_over = 0;  // test hook (KISS_HIP_FAIL_ALLOC_OVER, read when the ctx is created): see dmalloc
+    uint64_t fail_alloc_over = 0;  // test hook (kiss_hip_debug_fail_alloc_over): see dmalloc
     uint64_t m_cap0 = 0;           // != 0: the caller's choice of the default reservation (kiss_hip_ctx_create_sized)
     uint64_t t_cap = 0;            // capacity of the tied-segment arrays (suffixes still tied after round 0)
     uint64_t flags_cap = 0;        // u64 entries in `flags`

@@ -252,14 +252,14 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
         want_dna = oracle.suffix_sort(dna, 256)
         assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
         for k in (256, 0xFFFFFFFF):
-            monkeypatch.setenv("KISS_HIP_FAIL_ALLOC_OVER", "700000")
+            assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 700000) == 0
             with pytest.raises(kiss_amd.KissHipError) as e:
                 c.suffix_sort(acac, k)
             assert e.value.status == _lib.KISS_HIP_E_NOMEM
             with pytest.raises(kiss_amd.KissHipError) as e:             # still failing while memory is short, still cleanly
                 c.suffix_sort(acac, k)
             assert e.value.status == _lib.KISS_HIP_E_NOMEM
-            monkeypatch.delenv("KISS_HIP_FAIL_ALLOC_OVER")
+            assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 0) == 0
             assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
             assert np.array_equal(c.suffix_sort(acac, k), oracle.suffix_sort(acac, k))
     finally:
