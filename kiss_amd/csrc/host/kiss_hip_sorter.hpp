@@ -30,6 +30,12 @@ struct KissHipSorter {
     static int d = 0;
     return d;
   }
+  // non-empty: the LMS sort is sharded over these GPUs of the node by this process (kiss_hip_suffix_sort_dna_u32_multi;
+  // the induction runs on the first one) -- what `kiss suffix_sort --gpus N` selects
+  static std::vector<int>& devices() {
+    static std::vector<int> d;
+    return d;
+  }
 
   static void check(int rc, const char* where) {
     if (rc == KISS_HIP_OK) return;
@@ -50,6 +56,12 @@ struct KissHipSorter {
                                    std::size_t /*num_threads*/ = std::thread::hardware_concurrency(),
                                    int algo = KISS_HIP_ALGO_PARALLEL_SORTING) {
     SA_t SA(S.size() + 1);
+    if (!devices().empty()) {
+      check(kiss_hip_suffix_sort_dna_u32_multi(S.data(), S.size(), k, algo, reinterpret_cast<std::uint32_t*>(SA.data()),
+                                               devices().data(), static_cast<int>(devices().size())),
+            "kiss_hip_suffix_sort_dna_u32_multi");
+      return SA;
+    }
     check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k, algo, reinterpret_cast<std::uint32_t*>(SA.data()),
                                        device()),
           "kiss_hip_suffix_sort_dna_u32");

@@ -1,6 +1,6 @@
 // The header-only C++ facade a maintainer drops into the reference.
 //   no argument : compile/link check only (tests/test_abi.py, runs on a box without a GPU): exits 0 without device work
-//   "run" FILE  : really calls KissHipSorter / KissHipSorter2 / get_suffix_array on a GPU box and writes the three
+//   "run" FILE  : really calls KissHipSorter / KissHipSorter2 / get_suffix_array on a GPU box and writes the four
 //                 suffix arrays to FILE (u32 LE, concatenated) for tests/test_cli_gpu.py to compare with the ctypes path
 #include <concepts>
 #include <cstdio>
@@ -29,12 +29,17 @@ int main(int argc, char** argv) {
     std::string text(S.size(), 'A');
     for (std::size_t i = 0; i < S.size(); i++) text[i] = (char)('A' + S[i]);
     auto sc = biovoltron::KissHipSorter<>::get_suffix_array(std::string_view(text), 256u, 1);
-    if (sa.size() != S.size() + 1 || sb.size() != S.size() + 1 || sc.size() != S.size() + 1) return 3;
+    // the same sort sharded over two shares of device 0 by this process (what `kiss suffix_sort --gpus N` selects)
+    biovoltron::KissHipSorter<>::devices() = {0, 0};
+    auto sd = biovoltron::KissHipSorter<>::get_suffix_array_dna(S, 256u, 1);
+    biovoltron::KissHipSorter<>::devices().clear();
+    if (sa.size() != S.size() + 1 || sb.size() != S.size() + 1 || sc.size() != S.size() + 1 || sd.size() != S.size() + 1) return 3;
     std::FILE* f = std::fopen(argv[2], "wb");
     if (!f) return 4;
     std::fwrite(sa.data(), 4, sa.size(), f);
     std::fwrite(sb.data(), 4, sb.size(), f);
     std::fwrite(sc.data(), 4, sc.size(), f);
+    std::fwrite(sd.data(), 4, sd.size(), f);
     std::fclose(f);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "host_facade_check: %s\n", e.what());
