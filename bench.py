@@ -261,7 +261,7 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
     kms0 = st0["kernels"]["fm_query"]["ms"]
     t0 = time.perf_counter()
     for _ in range(steps):
-        r = f.query_batch(None, want_offsets=False, d_patterns=d_p)
+        f.query_batch(None, want_offsets=False, d_patterns=d_p, keep_on_device=True)  # ranges left in HBM, like the SA
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     st1 = f._ctx.stats()

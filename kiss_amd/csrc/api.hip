@@ -297,9 +297,14 @@ int kiss_need_ctx_words(kiss_hip_ctx *ctx)
     return dmalloc(ctx, &ctx->CTX, ctx->max_n + 2);
 }
 
-int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
+int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
 {
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     free_lms_side(ctx);
+    if (dbg)
+        fprintf(stderr, "[kiss_hip] lms_reserve(%llu): freed the old arrays in %.3f s\n", (unsigned long long)m_cap,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     const uint64_t before = ctx->ws_bytes;
     ctx->m_cap = m_cap;
     const uint64_t radix_tiles = m_cap / 2048 + 2; // sized for the smallest radix tile in use
@@ -342,16 +347,25 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap)
     // (all-tied inputs such as periodic texts end up at m_cap)
     uint64_t t0 = m_cap / 4 + (4ull << 20);
     if (t0 > m_cap) t0 = m_cap;
+    // a caller that knows how many tied items it is about to handle says so: one allocation of the tied-segment arrays
+    // instead of the default one followed by a regrow (large hipMallocs late in a process run at 20-30 GB/s)
+    if (t_cap_wanted > t0) t0 = t_cap_wanted;
     if (const char *e = getenv("KISS_HIP_TCAP0")) { // test hook: start small so that every growth path runs
         const unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 1 && v < t0) t0 = v;
     }
+    if (dbg)
+        fprintf(stderr, "[kiss_hip] lms_reserve(%llu): %.1f GB allocated, %.3f s so far\n", (unsigned long long)m_cap,
+                (double)ctx->lms_bytes / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
     return kiss_tied_reserve(ctx, t0);
 }
 
 int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
 {
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     free_tied(ctx);
+    const auto t_freed = std::chrono::steady_clock::now();
     if (t_cap < 1024) t_cap = 1024;
     const uint64_t before = ctx->ws_bytes;
     // `flags` also holds the per-tile words of the fused flag + compaction over all m (or, for the doubling phase,
@@ -380,6 +394,10 @@ int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
 #undef ALLOC
     } while (0);
     ctx->tied_bytes = ctx->ws_bytes - before;
+    if (dbg)
+        fprintf(stderr, "[kiss_hip] tied_reserve(%llu): free %.3f s, %.1f GB allocated in %.3f s (rc %d)\n",
+                (unsigned long long)t_cap, std::chrono::duration<double>(t_freed - t_begin).count(), (double)ctx->tied_bytes / 1e9,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_freed).count(), rc);
     if (rc == KISS_HIP_OK) {
         ctx->t_cap = t_cap;
         ctx->flags_cap = fcap;

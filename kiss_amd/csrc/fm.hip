@@ -21,6 +21,7 @@
 // Locate: patterns with more than FM_HEAVY occurrences (tandem repeats reach 10^6) get a workgroup of their own,
 // the rest stay one lane per pattern; both produce the reference's output order.
 #include "kiss_internal.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -29,6 +30,18 @@ constexpr int FM_THREADS = 256;
 // with one lane per pattern the longest one alone set the kernel time.
 constexpr uint32_t FM_HEAVY = 256;
 constexpr int FMH_THREADS = 512;
+// (Measured and dropped, round 3: patterns above 16 384 hits shared by 32 workgroups each -- on the bench text 3 286
+//  patterns hold 16 K .. 62 K hits, no single one dominates, and repeating the per-level bookkeeping 32 times tripled the
+//  kernel time; profiles/r03_fm_*.)
+// ... and patterns with more than FM_LIGHT occurrences a WAVE: with one lane per pattern a wave of the light kernel runs
+// as long as its busiest lane (the breadth-first walk of a 200-hit pattern is some 85 ranges of dependent look-ups), and
+// that tail was most of the locate time.  The wave form is the workgroup kernel with 64 threads.
+// Measured (1 M x 32-base patterns, dm-size index; locate kernel time at FM_LIGHT = 4 / 8 / 16 / 32 / 64 / 256:
+// 1.84 / 1.64 / 1.58 / 1.58 / 1.56 / 1.30 ms): the wave tier LOSES -- a wave per pattern pays four levels of dependent
+// look-ups however few hits there are, and there are hundreds of thousands of such patterns.  So the default keeps it
+// switched off (FM_LIGHT = FM_HEAVY: no pattern is "medium"); KISS_HIP_FM_LIGHT (1 .. 256) is the A-B hook.
+constexpr uint32_t FM_LIGHT_DEFAULT = 256;
+constexpr int FMM_THREADS = 64;
 
 struct FmiD {
     uint64_t N;
@@ -165,13 +178,15 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
                                                         uint32_t *__restrict__ beg_out, uint32_t *__restrict__ end_out,
                                                         uint64_t *__restrict__ cap /* offset slots per pattern */,
                                                         uint64_t *__restrict__ fcap /* frontier slots per pattern */,
-                                                        uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ nheavy)
+                                                        uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ nheavy,
+                                                        uint32_t *__restrict__ medium_list, uint32_t *__restrict__ nmedium,
+                                                        uint32_t FM_LIGHT)
 {
     uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
-    if (q >= Q) return;
-    uint64_t beg = 0, end = f.N;
-    const uint8_t *p = pat + q * L;
-    uint32_t len = L;
+    const bool live = q < Q; // (no early return: the list appends below are wave-wide)
+    uint64_t beg = 0, end = live ? f.N : 0;
+    const uint8_t *p = pat + (live ? q : 0) * L;
+    uint32_t len = live ? L : 0;
     if (!(end == beg || len == 0)) {
         while (len > 0) {
             if (end - beg < 1) break;
@@ -180,15 +195,30 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
             len--;
         }
     }
-    beg_out[q] = (uint32_t)beg;
-    end_out[q] = (uint32_t)end;
+    if (live) {
+        beg_out[q] = (uint32_t)beg;
+        end_out[q] = (uint32_t)end;
+    }
     // get_offsets (fm_index.hpp:472-482) tests `offsets.size() < end - beg` only BEFORE a range is taken from the queue
     // and then emits every sampled row of that range: on an index whose k-ordered SA ties long repeats (telomere-like
     // arrays under the k = 32 build) the walk returns MORE than end - beg positions.  Fewer than end - beg were out
     // before the last range and a range never holds more rows than the first one: at most 2 (end - beg) - 1 positions.
-    cap[q] = 2 * (end - beg) + 4;
-    fcap[q] = end - beg > FM_HEAVY ? 0 : (end - beg) + 4; // ranges of one level (rows of a level <= end - beg)
-    if (end - beg > FM_HEAVY) heavy_list[atomicAdd(nheavy, 1u)] = (uint32_t)q; // located by a workgroup (order irrelevant)
+    if (live) {
+        cap[q] = 2 * (end - beg) + 4;
+        fcap[q] = end - beg > FM_LIGHT ? 0 : (end - beg) + 4; // ranges of one level (rows of a level <= end - beg)
+    }
+    // located by a workgroup / by a wave (the order of the lists is irrelevant); the appends are aggregated per wave
+    const bool hv = live && end - beg > FM_HEAVY, md = live && !hv && end - beg > FM_LIGHT;
+    const uint64_t hm = __ballot(hv), mm = __ballot(md);
+    uint32_t hb = 0, mb = 0;
+    if (lane_id() == 0) {
+        if (hm) hb = atomicAdd(nheavy, (uint32_t)__popcll(hm));
+        if (mm) mb = atomicAdd(nmedium, (uint32_t)__popcll(mm));
+    }
+    hb = __shfl(hb, 0, 64);
+    mb = __shfl(mb, 0, 64);
+    if (hv) heavy_list[hb + (uint32_t)__popcll(hm & lanemask_lt())] = (uint32_t)q;
+    if (md) medium_list[mb + (uint32_t)__popcll(mm & lanemask_lt())] = (uint32_t)q;
 }
 
 // ---- locate: the reference's FIFO breadth-first walk, one lane per pattern ------------------------------
@@ -198,18 +228,20 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
                                                          const uint64_t *__restrict__ fcap_index,
                                                          uint2 *__restrict__ frontier0, uint2 *__restrict__ frontier1,
                                                          uint32_t *__restrict__ out, uint64_t *__restrict__ got_out,
-                                                         unsigned long long *__restrict__ totals)
+                                                         unsigned long long *__restrict__ totals,
+                                                         const uint32_t *__restrict__ overflow, uint32_t FM_LIGHT)
 {
     uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
     unsigned long long got = 0, sum = 0;
+    if (*overflow) return; // see k_fm_check
     if (q < Q) {
         const uint64_t b0 = beg_in[q], e0 = end_in[q];
-        const uint64_t want = e0 - b0 > FM_HEAVY ? 0 : e0 - b0; // heavy patterns: k_fm_locate_heavy
+        const uint64_t want = e0 - b0 > FM_LIGHT ? 0 : e0 - b0; // the others: k_fm_locate_group (a wave or a workgroup each)
         const uint64_t base = cap_index[q], fbase = fcap_index[q];
         const uint64_t capq = 2 * want + 4, fcapq = want + 4;
         uint2 *cur = frontier0 + fbase, *nxt = frontier1 + fbase;
         uint64_t ncur = 1;
-        if (e0 - b0 <= FM_HEAVY) cur[0] = make_uint2((uint32_t)b0, (uint32_t)e0); // (a heavy pattern owns no frontier slots)
+        if (e0 - b0 <= FM_LIGHT) cur[0] = make_uint2((uint32_t)b0, (uint32_t)e0); // (the others own no frontier slots)
         bool stop = false;
         for (int dep = 0; dep < 4 && !stop; dep++) {
             uint64_t nn = 0;
@@ -250,7 +282,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
             nxt = tmp;
             ncur = nn < fcapq ? nn : fcapq;
         }
-        if (e0 - b0 <= FM_HEAVY) got_out[q] = got < capq ? got : capq;
+        if (e0 - b0 <= FM_LIGHT) got_out[q] = got < capq ? got : capq;
         if (got > capq) got = capq; // can not happen (bound above); keeps totals consistent with the buffers
     }
     // wave-level reduction of (hits, checksum), one atomic pair per wave
@@ -270,18 +302,25 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_locate(FmiD f, const uint32_t
 // Same breadth-first walk and the same output order; a level has at most 4^depth <= 64 ranges, so wave 0 handles
 // the ranges (one lane each: sampled-row counts, the stop rule, the children) and then all threads write the
 // level's offsets -- output o belongs to the range whose prefix count covers it.
-__global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const uint32_t *__restrict__ beg_in,
+template <int THREADS> // FMH_THREADS: one workgroup per pattern; FMM_THREADS: one wave per pattern
+__global__ __launch_bounds__(THREADS) void k_fm_locate_group(FmiD f, const uint32_t *__restrict__ beg_in,
                                                                 const uint32_t *__restrict__ end_in,
                                                                 const uint32_t *__restrict__ heavy_list,
                                                                 const uint64_t *__restrict__ cap_index,
                                                                 uint32_t *__restrict__ out, uint64_t *__restrict__ got_out,
-                                                                unsigned long long *__restrict__ totals)
+                                                                unsigned long long *__restrict__ totals,
+                                                                const uint32_t *__restrict__ nheavy, // device-side count
+                                                                const uint32_t *__restrict__ overflow)
 {
     __shared__ uint2 fr[2][64];
     __shared__ uint32_t d_ob[64], d_pre[65];
     __shared__ uint32_t s_n, s_np, s_total, s_stop;
-    __shared__ unsigned long long s_sum[FMH_THREADS / 64];
-    const uint32_t q = heavy_list[blockIdx.x];
+    __shared__ unsigned long long s_sum[THREADS / 64];
+    if (*overflow) return; // the scratch of this batch does not fit what the ranges need: the host regrows and runs again
+    // the number of heavy patterns is only known on the device: the grid is a fixed number of workgroups that walk the list
+    for (uint32_t hq = blockIdx.x; hq < *nheavy; hq += gridDim.x) {
+    __syncthreads(); // (the shared arrays of the previous pattern are dead)
+    const uint32_t q = heavy_list[hq];
     const uint64_t b0 = beg_in[q], e0 = end_in[q];
     const uint64_t want = e0 - b0, base = cap_index[q], capq = 2 * want + 4;
     if (threadIdx.x == 0) {
@@ -359,17 +398,42 @@ __global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const u
         }
         __syncthreads();
         const uint32_t total = s_total, np = s_np;
-        for (uint32_t o = threadIdx.x; o < total; o += FMH_THREADS) {
-            uint32_t lo = 0, hi = np; // last processed range t with d_pre[t] <= o (ranges without sampled rows tie: the last one wins)
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (d_pre[mid] <= o) lo = mid;
-                else hi = mid;
+        // four outputs per thread and step: the four sampled-SA reads are independent (one round trip for four)
+        uint32_t lo_hint = 0; // a thread's outputs ascend: the range of the next one is never before this one's
+        for (uint32_t o0 = threadIdx.x; o0 < total; o0 += 4u * THREADS) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t o = o0 + (uint32_t)u * THREADS;
+                v[u] = 0;
+                if (o < total) {
+                    // last processed range t with d_pre[t] <= o (ranges without sampled rows tie: the last one wins);
+                    // mostly the range of the previous output or the next one: a short walk, then the binary search
+                    uint32_t lo = lo_hint;
+                    if (lo + 1 < np && d_pre[lo + 1] <= o) {
+                        lo++;
+                        if (lo + 1 < np && d_pre[lo + 1] <= o) {
+                            uint32_t hi = np;
+                            while (hi - lo > 1) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (d_pre[mid] <= o) lo = mid;
+                                else hi = mid;
+                            }
+                        }
+                    }
+                    lo_hint = lo;
+                    v[u] = f.sa[d_ob[lo] + (o - d_pre[lo])] + (uint32_t)dep;
+                }
             }
-            const uint32_t v = f.sa[d_ob[lo] + (o - d_pre[lo])] + (uint32_t)dep;
-            const uint64_t idx = got + o;
-            if (idx < capq) out[base + idx] = v;
-            sum += v;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t o = o0 + (uint32_t)u * THREADS;
+                if (o < total) {
+                    const uint64_t idx = got + o;
+                    if (idx < capq) out[base + idx] = v[u];
+                    sum += v[u];
+                }
+            }
         }
         got += total;
         const bool stop = s_stop != 0;
@@ -384,11 +448,25 @@ __global__ __launch_bounds__(FMH_THREADS) void k_fm_locate_heavy(FmiD f, const u
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long s = 0;
-        for (int w = 0; w < FMH_THREADS / 64; w++) s += s_sum[w];
+        for (int w = 0; w < THREADS / 64; w++) s += s_sum[w];
         const uint64_t g = got < capq ? got : capq;
         got_out[q] = g;
         atomicAdd(&totals[0], (unsigned long long)g);
         atomicAdd(&totals[1], s);
+    }
+    } // next heavy pattern of this workgroup
+}
+
+// the scratch of a batch is sized from the LAST batch of the ctx (no host read-back in the middle of a call): this
+// says whether it holds what the ranges of THIS batch need.  ctl[0] = overflow flag, ctl[1] / ctl[2] = needed entries.
+__global__ void k_fm_check(const uint64_t *__restrict__ cap_index, const uint64_t *__restrict__ fcap_index, uint64_t Q,
+                           uint64_t scratch_entries, uint64_t frontier_entries, uint64_t *__restrict__ need,
+                           uint32_t *__restrict__ overflow)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        need[0] = cap_index[Q];
+        need[1] = fcap_index[Q];
+        *overflow = (cap_index[Q] > scratch_entries || fcap_index[Q] + 1 > frontier_entries) ? 1u : 0u;
     }
 }
 
@@ -578,7 +656,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     f.b = fmi->b;
     f.b_occ = fmi->b_occ;
 
-    DevBuf cap, capidx, fcap, fcapidx, got, gotidx, tot, fr0, fr1, scratch, heavy, blocks;
+    DevBuf cap, capidx, fcap, fcapidx, got, gotidx, tot, fr0, fr1, scratch, heavy, medium, blocks;
     // the interleaved rank blocks, derived from the caller's arrays at the start of every batch (never kept: the arrays
     // may have changed between calls)
     const uint64_t nblocks = f.N / 64 + 1;
@@ -604,21 +682,30 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
                            (uint4 *)blocks.p);
         KCHECK(hipGetLastError());
     }
+    uint32_t fm_light = FM_LIGHT_DEFAULT;
+    if (const char *e = getenv("KISS_HIP_FM_LIGHT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= (int)FM_HEAVY) fm_light = (uint32_t)v;
+    }
     KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
+    KTRY(medium.take(ctx, 12, (Q + 2) * 4));
+    KTRY(kiss_zero_u32(ctx, medium.p, 1));
+
     KTRY(cap.take(ctx, 1, (Q + 1) * 8));
     KTRY(capidx.take(ctx, 2, (Q + 1) * 8));
     KTRY(fcap.take(ctx, 9, (Q + 1) * 8));
     KTRY(fcapidx.take(ctx, 10, (Q + 1) * 8));
     KTRY(got.take(ctx, 3, (Q + 1) * 8));
     KTRY(gotidx.take(ctx, 4, (Q + 1) * 8));
-    KTRY(tot.take(ctx, 5, 16));
+    KTRY(tot.take(ctx, 5, 64)); // [0] hits, [1] checksum, [2] offset-scratch entries needed, [3] frontier entries, [4] overflow
     const unsigned grid = (unsigned)div_up(Q, FM_THREADS);
     {
         KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
         if (timed) (void)hipEventRecord(sev[0], ctx->stream);
         hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
-                           (uint64_t *)cap.p, (uint64_t *)fcap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p);
+                           (uint64_t *)cap.p, (uint64_t *)fcap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p,
+                           (uint32_t *)medium.p + 1, (uint32_t *)medium.p, fm_light);
         if (timed) (void)hipEventRecord(sev[1], ctx->stream);
         KCHECK(hipGetLastError());
     }
@@ -626,30 +713,54 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
     KTRY(kiss_scan_u64(ctx, (const uint64_t *)cap.p, (uint64_t *)capidx.p, Q + 1));
     KTRY(kiss_zero_u32(ctx, (uint8_t *)fcap.p + Q * 8, 2));
     KTRY(kiss_scan_u64(ctx, (const uint64_t *)fcap.p, (uint64_t *)fcapidx.p, Q + 1));
-    uint64_t total_cap = 0, total_fcap = 0;
+    // The offset scratch and the frontier arrays are sized by what the PREVIOUS batch of this ctx needed (the pool keeps
+    // them): the locate kernels are queued right behind the scans, a one-thread kernel tells them on the device whether
+    // the buffers hold this batch, and the host learns the sizes with the totals at the end -- one synchronisation per
+    // call instead of two.  Only a batch that needs more than the pool holds (the first one, or a much heavier one) is
+    // located a second time after the pool has grown.
+    uint64_t *d_need = (uint64_t *)tot.p + 2;        // [2], [3] of the totals block
+    uint32_t *d_over = (uint32_t *)((uint64_t *)tot.p + 4);
+    uint64_t h[5] = {0, 0, 0, 0, 0};
     uint32_t nheavy = 0;
-    KCHECK(hipMemcpyAsync(&total_cap, (uint8_t *)capidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipMemcpyAsync(&total_fcap, (uint8_t *)fcapidx.p + Q * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipMemcpyAsync(&nheavy, heavy.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
-    KTRY(fr0.take(ctx, 6, (total_fcap + 1) * sizeof(uint2)));
-    KTRY(fr1.take(ctx, 7, (total_fcap + 1) * sizeof(uint2)));
-    KTRY(scratch.take(ctx, 8, total_cap * sizeof(uint32_t)));
-    KTRY(kiss_zero_u32(ctx, tot.p, 4));
-    {
-        KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
-        if (timed) (void)hipEventRecord(sev[2], ctx->stream);
-        hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
-                           (const uint64_t *)capidx.p, (const uint64_t *)fcapidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p,
-                           (uint32_t *)scratch.p,
-                           (uint64_t *)got.p, (unsigned long long *)tot.p);
-        if (nheavy)
-            hipLaunchKernelGGL(k_fm_locate_heavy, dim3(nheavy), dim3(FMH_THREADS), 0, ctx->stream, f, beg, end,
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const uint64_t scratch_entries = ctx->fm_pool_cap[8] / sizeof(uint32_t);
+        const uint64_t frontier_entries = (ctx->fm_pool_cap[6] < ctx->fm_pool_cap[7] ? ctx->fm_pool_cap[6] : ctx->fm_pool_cap[7]) / sizeof(uint2);
+        KTRY(fr0.take(ctx, 6, ctx->fm_pool_cap[6]));
+        KTRY(fr1.take(ctx, 7, ctx->fm_pool_cap[7]));
+        KTRY(scratch.take(ctx, 8, ctx->fm_pool_cap[8]));
+        KTRY(kiss_zero_u32(ctx, tot.p, 4));
+        hipLaunchKernelGGL(k_fm_check, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)capidx.p, (const uint64_t *)fcapidx.p, Q,
+                           scratch_entries, frontier_entries, d_need, d_over);
+        {
+            KTimer t(ctx, KISS_HIP_K_FM_QUERY, Q);
+            if (timed) (void)hipEventRecord(sev[2], ctx->stream);
+            hipLaunchKernelGGL(k_fm_locate, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, beg, end, Q,
+                               (const uint64_t *)capidx.p, (const uint64_t *)fcapidx.p, (uint2 *)fr0.p, (uint2 *)fr1.p,
+                               (uint32_t *)scratch.p, (uint64_t *)got.p, (unsigned long long *)tot.p, (const uint32_t *)d_over,
+                               fm_light);
+            const unsigned hgrid = (unsigned)(Q < 2048 ? Q : 2048);
+            hipLaunchKernelGGL((k_fm_locate_group<FMH_THREADS>), dim3(hgrid), dim3(FMH_THREADS), 0, ctx->stream, f, beg, end,
                                (const uint32_t *)heavy.p + 1, (const uint64_t *)capidx.p, (uint32_t *)scratch.p,
-                               (uint64_t *)got.p, (unsigned long long *)tot.p);
-        if (timed) (void)hipEventRecord(sev[3], ctx->stream);
-        KCHECK(hipGetLastError());
+                               (uint64_t *)got.p, (unsigned long long *)tot.p, (const uint32_t *)heavy.p, (const uint32_t *)d_over);
+            const unsigned mgrid = (unsigned)(Q < 16384 ? Q : 16384); // one wave per pattern, walking the medium list
+            hipLaunchKernelGGL((k_fm_locate_group<FMM_THREADS>), dim3(mgrid), dim3(FMM_THREADS), 0, ctx->stream, f, beg, end,
+                               (const uint32_t *)medium.p + 1, (const uint64_t *)capidx.p, (uint32_t *)scratch.p,
+                               (uint64_t *)got.p, (unsigned long long *)tot.p, (const uint32_t *)medium.p, (const uint32_t *)d_over);
+            if (timed) (void)hipEventRecord(sev[3], ctx->stream);
+            KCHECK(hipGetLastError());
+        }
+        KCHECK(hipMemcpyAsync(h, tot.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipMemcpyAsync(&nheavy, heavy.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+        if ((uint32_t)h[4] == 0) break; // the buffers held the batch
+        if (attempt) return KINTERNAL();
+        // grow the pool to what this batch needs and locate again (the ranges stand)
+        KTRY(fr0.take(ctx, 6, (h[3] + 1) * sizeof(uint2)));
+        KTRY(fr1.take(ctx, 7, (h[3] + 1) * sizeof(uint2)));
+        KTRY(scratch.take(ctx, 8, h[2] * sizeof(uint32_t)));
     }
+    const uint64_t total_cap = h[2];
+    (void)nheavy;
     if (offsets && offsets_index) {
         KTRY(kiss_zero_u32(ctx, (uint8_t *)got.p + Q * 8, 2));
         KTRY(kiss_scan_u64(ctx, (const uint64_t *)got.p, offsets_index, Q + 1));
@@ -660,9 +771,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
                                offsets_capacity);
         KCHECK(hipGetLastError());
     }
-    uint64_t h[2] = {0, 0};
-    KCHECK(hipMemcpyAsync(h, tot.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    KCHECK(hipStreamSynchronize(ctx->stream));
+    if (offsets && offsets_index) KCHECK(hipStreamSynchronize(ctx->stream)); // (the gather above)
     if (hit_count_total) *hit_count_total = h[0];
     if (checksum) *checksum = h[1];
     if (timed) { // the two halves of the query apart (they accumulate like ms_kernel[] until the next sort resets the stats)

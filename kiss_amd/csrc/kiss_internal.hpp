@@ -104,8 +104,8 @@ struct kiss_hip_ctx {
     uint64_t *pairs1 = nullptr, *pairs2 = nullptr;
     uint64_t pairs_cap = 0;
     // scratch of kiss_hip_fmi_query_batch_dev, kept between calls (fm.hip)
-    void *fm_pool[12] = {};
-    uint64_t fm_pool_cap[12] = {};
+    void *fm_pool[13] = {};
+    uint64_t fm_pool_cap[13] = {};
     // near-end
     uint32_t *near_idx = nullptr, *near_fin = nullptr, *near_pos = nullptr, *near_tmp = nullptr, *near_tmp2 = nullptr; // place.hip: near_reserve
     uint64_t near_cap = 0;
@@ -160,7 +160,7 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 
 // ---- stages (host drivers) -------------------------------------------------------
 // (re)allocates every LMS-sized array for at least m_cap suffixes
-int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap);
+int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted = 0);
 // (re)allocates the tied-segment arrays (seg*, slot*, segstart*, bkey*, bpos*, bseg*, bslot, flags) for t_cap items;
 // their contents are lost
 int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap);

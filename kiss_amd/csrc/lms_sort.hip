@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <utility>
 #include <vector>
 
@@ -1779,7 +1780,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             break;
         if (count > ctx->m_cap || count > ctx->t_cap) { // regrow the work buffers (their contents are dead); keeps CTX, pk
             const uint64_t want = count + count / 64 + 1024;
-            if (count > ctx->m_cap && (rc = kiss_lms_reserve(ctx, want))) break;
+            if (count > ctx->m_cap && (rc = kiss_lms_reserve(ctx, want, want))) break; // (both sets of arrays in one go)
             if (count > ctx->t_cap && (rc = kiss_tied_reserve(ctx, want))) break;
             if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
         }
@@ -1856,8 +1857,8 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             const uint64_t ncount = tot >> 32;
             nseg = tot & 0xFFFFFFFFull;
             if (dbg)
-                fprintf(stderr, "[kiss_hip] refine h=%llu: items %llu (longest group %s%u) -> %llu in %llu groups\n",
-                        (unsigned long long)h, (unsigned long long)count, maxlen ? "" : "<= ", maxlen ? maxlen : 64u,
+                fprintf(stderr, "[kiss_hip] refine h=%llu: (host clock %.3f s) items %llu (longest group %s%u) -> %llu in %llu groups\n",
+                        (unsigned long long)h, (double)clock() / CLOCKS_PER_SEC, (unsigned long long)count, maxlen ? "" : "<= ", maxlen ? maxlen : 64u,
                         (unsigned long long)ncount, (unsigned long long)nseg);
             count = ncount;
             std::swap(P, P2);

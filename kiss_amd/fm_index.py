@@ -185,9 +185,10 @@ class FMIndex:
         v.b_occ = self.b_occ.data_ptr()
         return v
 
-    def query_batch(self, patterns, want_offsets=True, d_patterns=None):
+    def query_batch(self, patterns, want_offsets=True, d_patterns=None, keep_on_device=False):
         """patterns: (Q, L) uint8 array with values 0..3 (host) or a device tensor via d_patterns.
-        Returns dict(beg, end, total_hits, checksum[, offsets, offsets_index])."""
+        Returns dict(beg, end, total_hits, checksum[, offsets, offsets_index]); keep_on_device: beg / end stay device
+        tensors (int32 holding the u32 values) instead of being copied to the host."""
         torch = _torch()
         dev = torch.device("cuda", self.device)
         if d_patterns is None:
@@ -226,8 +227,11 @@ class FMIndex:
                                                     ctypes.c_void_p(end.data_ptr()), ctypes.byref(tot),
                                                     ctypes.byref(chk), None, None, 0, None),
                    "kiss_hip_fmi_query_batch_dev", ctx._ctx)
-        res["beg"] = beg.cpu().numpy().view(np.uint32)
-        res["end"] = end.cpu().numpy().view(np.uint32)
+        if keep_on_device:
+            res["beg"], res["end"] = beg, end
+        else:
+            res["beg"] = beg.cpu().numpy().view(np.uint32)
+            res["end"] = end.cpu().numpy().view(np.uint32)
         res["total_hits"] = int(tot.value)
         res["checksum"] = int(chk.value)
         return res
