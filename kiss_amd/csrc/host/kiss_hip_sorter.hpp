@@ -23,8 +23,24 @@ namespace biovoltron {
 
 template <typename size_type = std::uint32_t>
 struct KissHipSorter {
-  static_assert(sizeof(size_type) == 4, "the HIP path implements the CLI's uint32_t index type (suffix_sort.hpp:37)");
+  // The device computes 32-bit indexes (the CLI's index type, suffix_sort.hpp:37; n <= KISS_HIP_MAX_N < 2^32).  A wider
+  // size_type (the reference's template takes any unsigned type, kiss1_sorter.hpp:7) gets the same values widened.
+  static_assert(sizeof(size_type) == 4 || sizeof(size_type) == 8, "size_type: uint32_t or uint64_t");
   using SA_t = std::vector<size_type>;
+
+  // runs `call(uint32_t* SA)` and returns the suffix array as SA_t
+  template <class F>
+  static SA_t with_u32(std::size_t n, F&& call) {
+    if constexpr (sizeof(size_type) == 4) {
+      SA_t SA(n + 1);
+      call(reinterpret_cast<std::uint32_t*>(SA.data()));
+      return SA;
+    } else {
+      std::vector<std::uint32_t> narrow(n + 1);
+      call(narrow.data());
+      return SA_t(narrow.begin(), narrow.end());
+    }
+  }
 
   static int& device() {
     static int d = 0;
@@ -55,17 +71,16 @@ struct KissHipSorter {
   static SA_t get_suffix_array_dna(const std::vector<std::uint8_t>& S, size_type k = 256u,
                                    std::size_t /*num_threads*/ = std::thread::hardware_concurrency(),
                                    int algo = KISS_HIP_ALGO_PARALLEL_SORTING) {
-    SA_t SA(S.size() + 1);
-    if (!devices().empty()) {
-      check(kiss_hip_suffix_sort_dna_u32_multi(S.data(), S.size(), k, algo, reinterpret_cast<std::uint32_t*>(SA.data()),
-                                               devices().data(), static_cast<int>(devices().size())),
-            "kiss_hip_suffix_sort_dna_u32_multi");
-      return SA;
-    }
-    check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k, algo, reinterpret_cast<std::uint32_t*>(SA.data()),
-                                       device()),
-          "kiss_hip_suffix_sort_dna_u32");
-    return SA;
+    // an order beyond 32 bits is the unbounded order (the CLI truncates -1 to 0xFFFFFFFF, suffix_sort.hpp:35-37)
+    const std::uint32_t k32 = static_cast<std::uint64_t>(k) > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<std::uint32_t>(k);
+    return with_u32(S.size(), [&](std::uint32_t* SA) {
+      if (!devices().empty())
+        check(kiss_hip_suffix_sort_dna_u32_multi(S.data(), S.size(), k32, algo, SA, devices().data(),
+                                                 static_cast<int>(devices().size())),
+              "kiss_hip_suffix_sort_dna_u32_multi");
+      else
+        check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k32, algo, SA, device()), "kiss_hip_suffix_sort_dna_u32");
+    });
   }
 
   // range overload, kiss1_sorter.hpp:10-18
@@ -79,10 +94,9 @@ struct KissHipSorter {
   static SA_t get_suffix_array(const std::ranges::random_access_range auto& ref, size_type /*k*/ = 256u,
                                std::size_t /*num_threads*/ = std::thread::hardware_concurrency()) {
     const auto S = prepare_aligned_ref(ref);
-    SA_t SA(S.size() + 1);
-    check(kiss_hip_suffix_sort_u8(S.data(), S.size(), reinterpret_cast<std::uint32_t*>(SA.data()), device()),
-          "kiss_hip_suffix_sort_u8");
-    return SA;
+    return with_u32(S.size(), [&](std::uint32_t* SA) {
+      check(kiss_hip_suffix_sort_u8(S.data(), S.size(), SA, device()), "kiss_hip_suffix_sort_u8");
+    });
   }
 };
 
@@ -91,7 +105,7 @@ struct KissHipSorter {
 template <typename size_type = std::uint32_t>
 struct KissHipSorter2 : KissHipSorter<size_type> {
   using SA_t = typename KissHipSorter<size_type>::SA_t;
-  static SA_t get_suffix_array_dna(const std::vector<std::uint8_t>& S, size_type k = 0xFFFFFFFFu,
+  static SA_t get_suffix_array_dna(const std::vector<std::uint8_t>& S, size_type k = static_cast<size_type>(0xFFFFFFFFu),
                                    std::size_t t = std::thread::hardware_concurrency()) {
     return KissHipSorter<size_type>::get_suffix_array_dna(S, k, t, KISS_HIP_ALGO_PREFIX_DOUBLING);
   }

@@ -36,13 +36,21 @@ constexpr uint32_t SMALL_SEG = 64;      // the doubling rounds of the exact-orde
 constexpr uint32_t LMS_SMALL_SEG = 24;
 constexpr int ROUND0_BASES = 20;
 
+// seg / segstart (optional): the members of a segment of exactly two get no key -- k_seg_finish compares such a pair
+// once, walking both suffixes from the segment's depth on, so the 32-base key would be one more random text read per
+// member for nothing (pairs are more than half of what survives round 0: the two copies of a duplicated stretch)
 __global__ __launch_bounds__(LS_THREADS) void k_gather_keys(const uint64_t *__restrict__ pk, uint64_t n,
                                                            const uint32_t *__restrict__ pos, uint64_t count,
                                                            uint64_t depth_off, uint64_t mask,
-                                                           uint64_t *__restrict__ key)
+                                                           uint64_t *__restrict__ key, const uint32_t *__restrict__ seg,
+                                                           const uint32_t *__restrict__ segstart)
 {
     uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= count) return;
+    if (seg) {
+        const uint32_t sg = seg[i];
+        if (segstart[sg + 1] - segstart[sg] == 2u) return;
+    }
     uint64_t q = (uint64_t)pos[i] + depth_off;
     uint64_t k = (q < n) ? kiss_key32(pk, q) : 0ull;
     key[i] = k & mask;
@@ -52,6 +60,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_gather_keys(const uint64_t *__re
 // compared up to depth (0 = unbounded), ties go to the smaller index (= smaller text position)
 // *tied (optional) is set when the walk reached the depth without a difference: the order then is the tie rule's, and
 // both suffixes are tainted for the exact-order finish (KISS_CTX_TAINT)
+// (off + 32 = the first base not yet compared: callers that have compared the 32-base key of the round pass `off`,
+//  the pair path of k_seg_finish, which has no key, passes off - 32 and lets the walk start at the segment's depth)
 __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint64_t n, uint64_t pi, uint64_t pj,
                                           uint64_t off, uint64_t depth, bool i_before_j, bool *tied = nullptr)
 {
@@ -180,7 +190,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
     bool taint = false;
     if (small) {
         pi = pos[i];
-        if (!second_in_wave) {
+        if (!second_in_wave && b - a == 2) {
+            // a pair: no keys were gathered for it (k_gather_keys); one walk from the segment's depth decides
+            const uint32_t j = (uint32_t)i == a ? a + 1 : a;
+            r = deep_less(pk, n, pos[j], pi, off - 32, depth, j < (uint32_t)i, &taint) ? 1u : 0u;
+        } else if (!second_in_wave) {
             const uint64_t ki = key[i];
             bool sorted = false;
             if (b - a >= 3) { // adjacent pairs all in order -> already sorted
@@ -1173,6 +1187,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         const int v = atoi(e);
         if (v >= 1 && v <= 8) pivot_slots = v;
     }
+    const bool no_pair_keys = getenv("KISS_HIP_PAIR_KEYS") == nullptr; // A-B hook: gather the round's key for pairs as well
     uint32_t small_seg = LMS_SMALL_SEG;
     if (const char *e = getenv("KISS_HIP_SMALL_SEG")) { // tuning hook
         int v = atoi(e);
@@ -1262,8 +1277,10 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         const unsigned grid = (unsigned)div_up(count, T);
         {
             KTimer t(ctx, KISS_HIP_K_KEYGATHER, count);
+            // (segstart's end entry is needed by the pair test: set it first)
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, (uint32_t *)nullptr);
             hipLaunchKernelGGL(k_gather_keys, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, Pc, count, off, mask,
-                               K1);
+                               K1, no_pair_keys ? Gc : (const uint32_t *)nullptr, SSc);
             KCHECK(hipGetLastError());
         }
         hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;

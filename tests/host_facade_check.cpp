@@ -12,6 +12,7 @@
 template <class T>
 concept SASorterLike = requires(T t, std::basic_string_view<signed char> ref) { t.get_suffix_array_dna(ref); };
 static_assert(SASorterLike<biovoltron::KissHipSorter<std::uint32_t>>);
+static_assert(SASorterLike<biovoltron::KissHipSorter<std::uint64_t>>);  // the reference's template takes a size_type (kiss1_sorter.hpp:7)
 
 int main(int argc, char** argv) {
   if (argc < 3 || std::strcmp(argv[1], "run") != 0) return 0;
@@ -33,6 +34,11 @@ int main(int argc, char** argv) {
     biovoltron::KissHipSorter<>::devices() = {0, 0};
     auto sd = biovoltron::KissHipSorter<>::get_suffix_array_dna(S, 256u, 1);
     biovoltron::KissHipSorter<>::devices().clear();
+    // 64-bit size_type: the same values, widened
+    auto s64 = biovoltron::KissHipSorter<std::uint64_t>::get_suffix_array_dna(S, 256u, 1);
+    if (s64.size() != sa.size()) return 5;
+    for (std::size_t i = 0; i < sa.size(); i++)
+      if (s64[i] != sa[i]) return 5;
     if (sa.size() != S.size() + 1 || sb.size() != S.size() + 1 || sc.size() != S.size() + 1 || sd.size() != S.size() + 1) return 3;
     std::FILE* f = std::fopen(argv[2], "wb");
     if (!f) return 4;
