@@ -36,20 +36,24 @@ constexpr uint32_t SMALL_SEG = 64;      // the doubling rounds of the exact-orde
 constexpr uint32_t LMS_SMALL_SEG = 24;
 constexpr int ROUND0_BASES = 20;
 
-// seg / segstart (optional): the members of a segment of exactly two get no key -- k_seg_finish compares such a pair
-// once, walking both suffixes from the segment's depth on, so the 32-base key would be one more random text read per
-// member for nothing (pairs are more than half of what survives round 0: the two copies of a duplicated stretch)
+// seg / segstart (optional): only members of segments of min_len .. max_len items get a key.  A segment of exactly two is
+// compared once by k_seg_finish, walking both suffixes from the segment's depth on, and a segment that goes to a pivot
+// round is keyed there against its reference string (k_pivot_lcp): for both the 32-base key would be one more random
+// text read per member for nothing (pairs are more than half of what survives round 0 -- the two copies of a duplicated
+// stretch --, the big segments most of the rest)
 __global__ __launch_bounds__(LS_THREADS) void k_gather_keys(const uint64_t *__restrict__ pk, uint64_t n,
                                                            const uint32_t *__restrict__ pos, uint64_t count,
                                                            uint64_t depth_off, uint64_t mask,
                                                            uint64_t *__restrict__ key, const uint32_t *__restrict__ seg,
-                                                           const uint32_t *__restrict__ segstart)
+                                                           const uint32_t *__restrict__ segstart, uint32_t min_len,
+                                                           uint32_t max_len)
 {
     uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= count) return;
     if (seg) {
         const uint32_t sg = seg[i];
-        if (segstart[sg + 1] - segstart[sg] == 2u) return;
+        const uint32_t len = segstart[sg + 1] - segstart[sg];
+        if (len < min_len || len > max_len) return;
     }
     uint64_t q = (uint64_t)pos[i] + depth_off;
     uint64_t k = (q < n) ? kiss_key32(pk, q) : 0ull;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__re
     uint64_t e = ex[i];
     uint32_t kx = (uint32_t)(e >> 32);
     const uint32_t sid = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
-    bkey[kx] = key[i];
+    if (key) bkey[kx] = key[i]; // (null: a pivot round follows, which keys the members against its reference string)
     bpos[kx] = pos[i];
     bslot[kx] = slot[i]; // slots stay in index order: the k-th item after the sort takes the k-th slot
     bseg[kx] = sid;
@@ -1275,12 +1279,14 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         const uint64_t mask = rem >= 32 ? ~0ull : (~0ull << (64 - 2 * rem));
         const int key_lo_bit = (int)(64 - 2 * rem);
         const unsigned grid = (unsigned)div_up(count, T);
+        // big segments need the round's key only where they are radix sorted on it (no pivot round ahead)
+        const bool pivot_ahead = depth && (off > ROUND0_BASES || pivot_r1) && pivot_on;
         {
             KTimer t(ctx, KISS_HIP_K_KEYGATHER, count);
             // (segstart's end entry is needed by the pair test: set it first)
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, (uint32_t *)nullptr);
             hipLaunchKernelGGL(k_gather_keys, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, Pc, count, off, mask,
-                               K1, no_pair_keys ? Gc : (const uint32_t *)nullptr, SSc);
+                               K1, no_pair_keys ? Gc : (const uint32_t *)nullptr, SSc, 3u, pivot_ahead ? small_seg : 0xFFFFFFFFu);
             KCHECK(hipGetLastError());
         }
         hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;
@@ -1328,8 +1334,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         const unsigned bgrid = (unsigned)div_up(nbig, T);
         {
             KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-            hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, K1, Pc, Sc, count, F1, F2,
-                               ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot, bss);
+            hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, pivot_ahead ? (const uint64_t *)nullptr : K1, Pc,
+                               Sc, count, F1, F2, ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot, bss);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, bss + nbigseg, (uint32_t)nbig, (uint32_t *)nullptr);
             KCHECK(hipGetLastError());
         }
@@ -1341,7 +1347,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         // long tandem arrays
         if (off == ROUND0_BASES) NE = nullptr;
         // ---- pivot round (bounded depth): see k_pivot_lcp
-        if (depth && (off > ROUND0_BASES || pivot_r1) && pivot_on) {
+        if (pivot_ahead) {
             const int dbits = bits_for(depth - off);          // d < depth - off
             int slots = 63 / (dbits + 4);                     // deviations per key: [side 2 | d | base 2] each + 1 bit
             if (slots > pivot_slots) slots = pivot_slots;
