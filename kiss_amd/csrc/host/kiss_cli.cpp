@@ -77,18 +77,27 @@ struct DeviceText {
     uint8_t *d_S = nullptr;
     uint64_t n = 0;
     double create_s = 0, load_s = 0;
-    DeviceText(const std::string &path, int device)
+    bool own_ctx = true;
+    // borrowed != nullptr: load through a context that something else owns (the first device's context of a
+    // kiss_hip_multi: one set of work arrays serves the loader and the sort; allocating a second set after freeing the
+    // first costs seconds on this driver -- profiles/r03_first_call_allocation_times_*.log)
+    DeviceText(const std::string &path, int device, kiss_hip_ctx *borrowed = nullptr)
     {
         uint64_t bytes = 0;
         if (kiss_hip_file_size(path.c_str(), &bytes) != KISS_HIP_OK) throw std::runtime_error("cannot open " + path);
         auto t0 = std::chrono::steady_clock::now();
-        check(kiss_hip_ctx_create(&ctx, device, bytes ? bytes : 1), "kiss_hip_ctx_create");
+        if (borrowed) {
+            ctx = borrowed;
+            own_ctx = false;
+        } else {
+            check(kiss_hip_ctx_create(&ctx, device, bytes ? bytes : 1), "kiss_hip_ctx_create");
+        }
         create_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         t0 = std::chrono::steady_clock::now();
         const int rc = kiss_hip_ctx_load_text_file(ctx, path.c_str(), &d_S, &n);
         load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc != KISS_HIP_OK) {
-            kiss_hip_ctx_destroy(ctx);
+            if (own_ctx) kiss_hip_ctx_destroy(ctx);
             throw std::runtime_error(std::string("kiss_hip_ctx_load_text_file: ") + kiss_hip_strerror(rc));
         }
     }
@@ -98,16 +107,10 @@ struct DeviceText {
         check(kiss_hip_copy_to_host(S.data(), d_S, n), "kiss_hip_copy_to_host");
         return S;
     }
-    // the multi-device path brings its own per-device contexts: give this one's workspace back, keep the text
-    void release_ctx()
-    {
-        if (ctx) kiss_hip_ctx_destroy(ctx);
-        ctx = nullptr;
-    }
     ~DeviceText()
     {
         kiss_hip_free_dev(d_S);
-        if (ctx) kiss_hip_ctx_destroy(ctx);
+        if (ctx && own_ctx) kiss_hip_ctx_destroy(ctx);
     }
     DeviceText(const DeviceText &) = delete;
     DeviceText &operator=(const DeviceText &) = delete;
@@ -266,7 +269,24 @@ struct Fmi {
 
 int suffix_sort_main(const Args &a)
 {
-    DeviceText T(a.fasta, a.device);
+    const bool multi = a.devices.size() > 1;
+    kiss_hip_multi *mc = nullptr;
+    double multi_create_s = 0;
+    if (multi) { // one process, several devices: the per-device contexts come first, the first one also loads the file
+        uint64_t bytes = 0;
+        if (kiss_hip_file_size(a.fasta.c_str(), &bytes) != KISS_HIP_OK) throw std::runtime_error("cannot open " + a.fasta);
+        const auto tc = std::chrono::steady_clock::now();
+        check(kiss_hip_multi_create(&mc, a.devices.data(), (int)a.devices.size(), bytes ? bytes : 1), "kiss_hip_multi_create");
+        multi_create_s = seconds_since(tc);
+    }
+    struct McGuard {
+        kiss_hip_multi *&m;
+        ~McGuard()
+        {
+            if (m) kiss_hip_multi_destroy(m);
+        }
+    } mc_guard{mc};
+    DeviceText T(a.fasta, a.device, multi ? kiss_hip_multi_ctx(mc, 0) : nullptr);
     int algo;
     if (a.algo == "PARALLEL_SORTING") algo = KISS_HIP_ALGO_PARALLEL_SORTING;
     else if (a.algo == "PREFIX_DOUBLING") algo = KISS_HIP_ALGO_PREFIX_DOUBLING;
@@ -276,15 +296,6 @@ int suffix_sort_main(const Args &a)
     const auto ta = std::chrono::steady_clock::now();
     check(kiss_hip_alloc_dev(&d_SA, (T.n + 1) * sizeof(uint32_t)), "kiss_hip_alloc_dev");
     const double alloc_s = seconds_since(ta);
-    const bool multi = a.devices.size() > 1;
-    kiss_hip_multi *mc = nullptr;
-    double multi_create_s = 0;
-    if (multi) { // one process, several devices: per-device contexts of their own (the loader's workspace goes back first)
-        T.release_ctx();
-        const auto tc = std::chrono::steady_clock::now();
-        check(kiss_hip_multi_create(&mc, a.devices.data(), (int)a.devices.size(), T.n ? T.n : 1), "kiss_hip_multi_create");
-        multi_create_s = seconds_since(tc);
-    }
     const auto t0 = std::chrono::steady_clock::now(); // the reference starts its stopwatch here (suffix_sort.hpp:57)
     if (multi)
         check(kiss_hip_multi_suffix_sort_dna_u32_dev(mc, T.d_S, T.n, k, algo, (uint32_t *)d_SA),
@@ -327,7 +338,6 @@ int suffix_sort_main(const Args &a)
         }
     }
     const auto tf = std::chrono::steady_clock::now();
-    if (mc) kiss_hip_multi_destroy(mc);
     kiss_hip_free_dev(d_SA);
     if (a.verbose) std::fprintf(stderr, "[debug] SA buffer released in %.6f s\n", seconds_since(tf));
     return 0;

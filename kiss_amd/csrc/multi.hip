@@ -477,6 +477,8 @@ int kiss_hip_multi_create(kiss_hip_multi **out, const int *devices, int ndev, ui
             }
             (void)hipGetLastError();
         }
+    // devices[0] runs the induction: its context words (4 bytes per base) are allocated here, not inside the first sort
+    if (!rc && hipSetDevice(devices[0]) == hipSuccess) rc = kiss_need_ctx_words(mc->ctx[0]);
     if (rc) {
         multi_free(mc);
         return rc;
