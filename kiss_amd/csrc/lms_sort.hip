@@ -395,7 +395,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__rest
                                                          const uint32_t *__restrict__ bseg,
                                                          const uint32_t *__restrict__ bsegstart, uint64_t nbig,
                                                          uint64_t off, uint64_t depth, int dbits, int slots,
-                                                         uint64_t *__restrict__ keyout, int frac_den)
+                                                         uint64_t *__restrict__ keyout, int frac_den, int with_ctx)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= nbig) return;
@@ -465,7 +465,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__rest
     }
     key <<= (uint64_t)slotbits * (uint64_t)(slots - used); // unused slots: zeros (only behind a terminator)
     key = (key << 1) | (complete ? 1ull : 0ull);
-    keyout[i] = key << (64 - (slots * slotbits + 1));
+    // The low 24 bits of the word are not sorted on (with_ctx: the key ends at bit 24 or above) and carry the member's
+    // short context word, like the low bits of a round-0 key: a member that retires in this round gets its word without
+    // the random text gather of the induction (the bases in front of the member sit in the sector this walk has read)
+    keyout[i] = (key << (64 - (slots * slotbits + 1))) | (with_ctx ? (uint64_t)kiss_load_ctx_n(pk, bpos[i], KISS_KEY_CTX_BASES) : 0ull);
 }
 
 // boundaries of the new segments in the sorted list: one byte per item, 1 = (segment, key) differs from the predecessor's,
@@ -473,17 +476,18 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_lcp(const uint64_t *__rest
 // it and its successor both start a "segment", which makes it a singleton for the compaction)
 __global__ __launch_bounds__(LS_THREADS) void k_pivot_heads(const uint64_t *__restrict__ key,
                                                            const uint32_t *__restrict__ seg, uint64_t nbig,
-                                                           int complete_bit, uint8_t *__restrict__ heads)
+                                                           int complete_bit, uint8_t *__restrict__ heads,
+                                                           uint64_t cmp_mask) // the key bits (a payload may sit below them)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     if (i >= nbig) return;
-    const uint64_t k = key[i];
+    const uint64_t k = key[i] & cmp_mask;
     const bool complete = ((k >> complete_bit) & 1ull) != 0;
-    const bool same_prev = i > 0 && seg[i] == seg[i - 1] && key[i - 1] == k;
+    const bool same_prev = i > 0 && seg[i] == seg[i - 1] && (key[i - 1] & cmp_mask) == k;
     uint8_t h = 1;
     if (same_prev && !complete) h = 0;
     // bit 1: a complete key shared with a neighbour = equal through the full depth: final here by the tie rule (taint)
-    if (complete && (same_prev || (i + 1 < nbig && seg[i + 1] == seg[i] && key[i + 1] == k))) h |= 2;
+    if (complete && (same_prev || (i + 1 < nbig && seg[i + 1] == seg[i] && (key[i + 1] & cmp_mask) == k))) h |= 2;
     heads[i] = h;
 }
 
@@ -573,7 +577,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ isa,
                                                           uint32_t *__restrict__ octx,
-                                                          uint32_t *__restrict__ tmark) // taint marks of retiring items
+                                                          uint32_t *__restrict__ tmark, // taint marks of retiring items
+                                                          const uint64_t *__restrict__ payload) // optional, with tmark: words
+                                                          // whose low KISS_KEY_CTX bits are the items' context words
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -621,7 +627,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             if (octx) octx[sl] = 0; // tied so far: its context word is gathered at placement
         } else {
             if (out) out[sl] = p;
-            if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
+            if (tmark && payload) // the word came along with the sort key (k_pivot_lcp)
+                tmark[sl] = (uint32_t)(payload[i] & KISS_KEY_CTX_MASK) | (((tl >> j) & 1u) ? KISS_CTX_TAINT : 0u);
+            else if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
             if (isa) isa[p] = sl;
             if constexpr (SRC != FC_HEADS) {
                 if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
@@ -1093,7 +1101,7 @@ template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
                uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr, uint32_t *nctx = nullptr,
-               bool *nctx_written = nullptr, uint32_t *tmark = nullptr)
+               bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr)
 {
     if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
@@ -1111,7 +1119,7 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     else // (without slots an item's slot is its index: out == pos means the list is in place already)
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
-                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark);
+                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -1353,10 +1361,12 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             if (slots > pivot_slots) slots = pivot_slots;
             const int kbits = slots * (dbits + 4) + 1;
             const int key_lo = 64 - 8 * ((kbits + 7) / 8);
+            // room for the members' context words below the sorted bits (k = 256: 40 key bits, 24 bits free)
+            const bool with_ctx = key_lo >= 24 && getenv("KISS_HIP_NO_PIVOT_CTX") == nullptr; // (A-B hook)
             {
                 KTimer t(ctx, KISS_HIP_K_SEGRANK, nbig);
                 hipLaunchKernelGGL(k_pivot_lcp, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->pk, ctx->bposA, ctx->bsegA, bss, nbig,
-                                   off, depth, dbits, slots, ctx->bkeyB, pivot_den[pivot_rounds_done % 3]);
+                                   off, depth, dbits, slots, ctx->bkeyB, pivot_den[pivot_rounds_done % 3], with_ctx ? 1 : 0);
                 pivot_rounds_done++;
                 KCHECK(hipGetLastError());
             }
@@ -1396,14 +1406,14 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             {
                 KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
                 hipLaunchKernelGGL(k_pivot_heads, dim3(bgrid), dim3(T), 0, ctx->stream, pb.key[pres], sseg, nbig, 64 - kbits,
-                                   heads);
+                                   heads, ~0ull << (64 - kbits));
                 KCHECK(hipGetLastError());
             }
             KTRY((fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, nbig, 0, 0, d_total)));
             KTRY(fc_read_total(ctx, d_total, &tot));
             KTRY((fc_compact<FC_HEADS, true>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, pb.pos[pres], ctx->bslot,
                                             nbig, 0, 0, Pc, Sc, Gc, SSc, ctx->lms_sorted_far, nullptr, nullptr, nullptr, nullptr,
-                                            ctx->lms_ctx_far)));
+                                            ctx->lms_ctx_far, with_ctx ? pb.key[pres] : (const uint64_t *)nullptr)));
             ctx->stats.big_item_rounds += nbig;
             count = tot >> 32;
             nseg = tot & 0xFFFFFFFFull;
