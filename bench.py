@@ -59,7 +59,7 @@ DOMINANT_CLASS = "radix_scatter"  # timed inside the timed region; bench checks 
 # profiles/r02_pmc_write_tcc_n5e8.csv, round 1: r01_pmc_*; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
 # streaming reads) per algorithmic byte of the same launches (n = 5e8, 41 dispatches of k_radix_scatter<0,false,true>: the
 # five round-0 passes of 145.4e6 items plus the small chain-collapse sorts): (2 x 4.609e6 KB + 9.271e6 KB) /
-# (5 x 145.4e6 x 24 B + <= 0.3e9 B) = 1.04 .. 1.06 in both rounds (the kernel is unchanged)
+# (5 x 145.4e6 x 24 B + <= 0.3e9 B) = 1.04 .. 1.06 in all three rounds (the kernel is unchanged; round 3: profiles/r03_pmc_*.csv)
 MEASURED_TRAFFIC_PER_ALGO_BYTE = {"radix_scatter": 1.05}
 
 
@@ -442,7 +442,7 @@ def roofline_of(agg, prof_agg, steps, prof_steps, profile_all):
             "traffic": (bytes_per_launch * MEASURED_TRAFFIC_PER_ALGO_BYTE[name]
                         if name in MEASURED_TRAFFIC_PER_ALGO_BYTE else None),
             "traffic_note": "bytes per launch = algorithmic bytes x the PMC-measured traffic ratio of this "
-                            "kernel (separate rocprofv3 --pmc runs, profiles/r02_pmc_*.csv)",
+                            "kernel (separate rocprofv3 --pmc runs, profiles/r03_pmc_*.csv)",
             "avg_launch_us": 1e6 * avg_s, "launches_per_step": a["launches"] / a_steps,
             "measured_in": ("timed region (HIP events around this class only)" if in_timed_region and not profile_all else
                             "timed region (HIP events around every class)" if in_timed_region else
