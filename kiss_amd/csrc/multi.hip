@@ -36,17 +36,32 @@ struct Barrier {
     std::condition_variable cv;
     int n = 1, waiting = 0;
     uint64_t gen = 0;
+    bool aborted = false; // a rank thread could not be started: nobody waits for it any more
     void arrive()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return;
         const uint64_t g = gen;
         if (++waiting == n) {
             waiting = 0;
             gen++;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return gen != g; });
+            cv.wait(lk, [&] { return gen != g || aborted; });
         }
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
+    }
+    void reset(int parties)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        n = parties;
+        waiting = 0;
+        aborted = false;
     }
 };
 
@@ -174,8 +189,11 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     mc->bar.arrive();
     mark(1);
     // ---- classify slice r; histogram of the first key bits of its far suffixes
-    auto classify = [&]() -> int {
+    // publish: the first classification of an attempt tells the other ranks its numbers (they read them after the next
+    // barrier); a repeat after a regrow gives the same numbers and leaves the shared block alone (others may be reading)
+    auto classify = [&](bool publish) -> int {
         KTRY(kiss_classify(ctx, n, sh->depth, lo, hi));
+        if (!publish) return (ctx->m == sh->m_local[r] && ctx->m_far == sh->m_far_local[r]) ? KISS_HIP_OK : KINTERNAL();
         for (int i = 0; i < 12; i++) sh->counts[r][i] = ctx->counts[i];
         sh->counts[r][12] = ctx->m_far;
         sh->m_local[r] = ctx->m;
@@ -185,7 +203,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     if (ok()) {
         int rc = KISS_HIP_OK;
         if (r > 0) rc = copy_between(mc, r, ctx->pk, 0, mc->ctx[0]->pk, words * sizeof(uint64_t), ctx->stream);
-        if (!rc) rc = classify();
+        if (!rc) rc = classify(true);
         if (!rc && G > 1) {
             rc = kiss_key_hist(ctx, ctx->keyA, ctx->m_far, MG_HIST_BITS, mc->d_hist[r]);
             if (!rc && hipMemcpyAsync(mc->h_hist[r], mc->d_hist[r], bins * sizeof(uint64_t), hipMemcpyDeviceToHost,
@@ -227,7 +245,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
         if (r == 0 && m_far_total + near_total > need) need = m_far_total + near_total;
         if (need > ctx->m_cap) { // regrow (contents lost) and classify the slice again: skewed key ranges, (AC)^n
             rc = kiss_lms_reserve(ctx, need + need / 64 + 1024);
-            if (!rc) rc = classify();
+            if (!rc) rc = classify(false);
         }
         // the near-end suffixes (only the rank(s) owning the end of the text have any) are set aside: the exchange
         // overwrites the tail of the ascending list they sit in
@@ -347,7 +365,7 @@ int multi_sort_dev(kiss_hip_multi *mc, const uint8_t *d_S, uint64_t n, uint32_t 
     }
     // (PREFIX_DOUBLING with a bounded k: the deterministic k-ordered array, like the single-device entry)
     mc->status.store(KISS_HIP_OK);
-    mc->bar.n = G;
+    mc->bar.reset(G);
     clk::time_point marks[8];
     const clk::time_point t_begin = clk::now();
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -375,9 +393,19 @@ int multi_sort_dev(kiss_hip_multi *mc, const uint8_t *d_S, uint64_t n, uint32_t 
             body(0);
         } else {
             std::vector<std::thread> th;
-            for (int r = 1; r < G; r++) th.emplace_back(body, r);
-            body(0);
+            bool started_all = true;
+            try {
+                th.reserve((size_t)G);
+                for (int r = 1; r < G; r++) th.emplace_back(body, r);
+            } catch (...) { // no exception crosses the ABI: the ranks that did start are let through their barriers
+                started_all = false;
+                int expect = KISS_HIP_OK;
+                mc->status.compare_exchange_strong(expect, KISS_HIP_E_NOMEM);
+                mc->bar.abort();
+            }
+            if (started_all) body(0);
             for (auto &t : th) t.join();
+            if (!started_all) mc->bar.reset(G);
         }
         if (mc->status.load() != KISS_HIP_OK) break;
         if (!mc->deep.load()) break;
