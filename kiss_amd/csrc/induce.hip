@@ -527,7 +527,10 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
 //   the last element of a chain appends its predecessor to another bucket during round r(v), so those
 //   terminal items are ordered by (r, item) inside their bucket  ->  one more small stable sort.
 // Items whose run reaches the cap R continue from the last block in the next call.
-constexpr uint64_t COLLAPSE_N = 1ull << 21;
+// rounds of at most this many items end in the closed form.  Round 3 sweep at chm13 size (induction ms per sort): 16 K 23.7,
+// 32 K 21.4, 64 K 21.2, 128 K 21.2, 256 K 21.2, 512 K 21.2, 1 M 22.2, 2 M (rounds 1-2) 23.2, 4 M 24.9, 8 M 27.1 -- the closed
+// form pays a scan, an expansion and two small radix sorts per call, a plain round of that size a count and a scatter
+constexpr uint64_t COLLAPSE_N = 1ull << 18;
 constexpr uint32_t COLLAPSE_RCAP = 65535;
 constexpr uint32_t COLLAPSE_RCAP_WIDE = (1u << 22) - 1; // runs of one base longer than 65535: wider steps
 constexpr int CH_THREADS = 256;
@@ -875,7 +878,12 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
     uint64_t tot[4];
     bool done;
     if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "induce start"));
-    uint64_t collapse_max = COLLAPSE_N < ctx->m_cap ? COLLAPSE_N : ctx->m_cap; // chain scratch: m_cap- and t_cap-sized arrays
+    uint64_t collapse_n = COLLAPSE_N;
+    if (const char *e = getenv("KISS_HIP_COLLAPSE_N")) { // tuning hook: rounds of at most this many items end in the closed form
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 1024 && v <= (1ull << 26)) collapse_n = v;
+    }
+    uint64_t collapse_max = collapse_n < ctx->m_cap ? collapse_n : ctx->m_cap; // chain scratch: m_cap- and t_cap-sized arrays
     if (collapse_max > ctx->t_cap) collapse_max = ctx->t_cap;
 
     const LmsRemap lms_rm{ctx->rm_fin, ctx->rm_pos, ctx->rm_E};
