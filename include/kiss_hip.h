@@ -40,7 +40,7 @@ typedef enum kiss_hip_status {
     KISS_HIP_E_INTERNAL = -6,    /* an internal invariant failed (bug) */
     KISS_HIP_E_IO = -7,          /* a file could not be opened / read */
     KISS_HIP_E_DEEP = -8         /* stage_sort only: exact order (k >= n) asked of the 32-bases-per-round path on ties
-                                    deeper than 32768 bases; sort with k = 256 and finish with stage_refine_exact
+                                    deeper than 32768 bases; sort with a bounded k (512) and finish with stage_refine_exact
                                     (the single-call entry points do this by themselves) */
 } kiss_hip_status;
 
@@ -288,8 +288,8 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
 int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
                           const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
                           const uint64_t counts12[12], uint32_t *d_SA, void *stream);
-/* stage_refine_exact: turns the h0-ordered suffix array of the text packed by stage_classify (h0 = 256: the output of the
- * stages run with k = 256) into the exact suffix array by rank doubling over the tied suffixes -- what
+/* stage_refine_exact: turns the h0-ordered suffix array of the text packed by stage_classify (h0 = 512, say: the output of the
+ * stages run with k = h0) into the exact suffix array by rank doubling over the tied suffixes -- what
  * kiss2_suffix_array_dna's prefix doubling yields for k = -1 (kiss2_core.hpp:728-797, 835-886).  Needs n >= 4 h0 + 1024. */
 int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, void *stream);
 

@@ -201,7 +201,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
     // the tied suffixes; texts too short for that go through the unbounded comparison directly.
     uint32_t h0 = 0;
     if (algo == KISS_HIP_ALGO_PREFIX_DOUBLING) {
-        h0 = 256;
+        h0 = KISS_EXACT_H0;
         if (const char *e = getenv("KISS_HIP_DOUBLING_H0")) { // tuning hook: 32 <= h0
             const int v = atoi(e);
             if (v >= 32 && v <= (1 << 20)) h0 = (uint32_t)v;
@@ -224,11 +224,11 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         if ((rc = kiss_classify(ctx, n, depth, 0, n))) break;
         (void)hipEventRecord(ev[2], ctx->stream);
         rc = kiss_lms_sort(ctx, n, k, depth);
-        if (rc == KISS_INTERNAL_TOO_DEEP && attempt == 0 && n >= 4ull * 256 + 1024) {
+        if (rc == KISS_INTERNAL_TOO_DEEP && attempt == 0 && n >= 4ull * KISS_EXACT_H0 + 1024) {
             // exact order requested through PARALLEL_SORTING on a text with very long repeats: same result via
             // the bounded phase + rank doubling (the k-ordered stage outputs then belong to k = 256)
             (void)hipStreamSynchronize(ctx->stream);
-            h0 = 256;
+            h0 = KISS_EXACT_H0;
             k = h0;
             depth = (uint64_t)KISS_STRIDE * ((uint64_t)k / KISS_STRIDE + 1);
             ctx->stats.refine_depth = h0;
@@ -504,7 +504,7 @@ const char *kiss_hip_strerror(int status)
     case KISS_HIP_E_UNSUPPORTED: return "request outside the implemented range";
     case KISS_HIP_E_INTERNAL: return "internal invariant violated";
     case KISS_HIP_E_IO: return "file could not be opened or read";
-    case KISS_HIP_E_DEEP: return "ties deeper than the bounded-round exact path handles: use k = 256 + stage_refine_exact";
+    case KISS_HIP_E_DEEP: return "ties deeper than the bounded-round exact path handles: sort with a bounded k, then stage_refine_exact";
     default: return "unknown status";
     }
 }

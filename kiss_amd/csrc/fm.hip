@@ -40,7 +40,7 @@ constexpr int FMH_THREADS = 512;
 // 1.84 / 1.64 / 1.58 / 1.58 / 1.56 / 1.30 ms): the wave tier LOSES -- a wave per pattern pays four levels of dependent
 // look-ups however few hits there are, and there are hundreds of thousands of such patterns.  So the default keeps it
 // switched off (FM_LIGHT = FM_HEAVY: no pattern is "medium"); KISS_HIP_FM_LIGHT (1 .. 256) is the A-B hook.
-constexpr uint32_t FM_LIGHT_DEFAULT = 256;
+// (default: FM_LIGHT = the workgroup threshold, i.e. no wave tier)
 constexpr int FMM_THREADS = 64;
 
 struct FmiD {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
                                                         uint64_t *__restrict__ fcap /* frontier slots per pattern */,
                                                         uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ nheavy,
                                                         uint32_t *__restrict__ medium_list, uint32_t *__restrict__ nmedium,
-                                                        uint32_t FM_LIGHT)
+                                                        uint32_t FM_LIGHT, uint32_t fm_heavy)
 {
     uint64_t q = (uint64_t)blockIdx.x * FM_THREADS + threadIdx.x;
     const bool live = q < Q; // (no early return: the list appends below are wave-wide)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(FM_THREADS) void k_fm_range(FmiD f, const uint8_t *
         fcap[q] = end - beg > FM_LIGHT ? 0 : (end - beg) + 4; // ranges of one level (rows of a level <= end - beg)
     }
     // located by a workgroup / by a wave (the order of the lists is irrelevant); the appends are aggregated per wave
-    const bool hv = live && end - beg > FM_HEAVY, md = live && !hv && end - beg > FM_LIGHT;
+    const bool hv = live && end - beg > fm_heavy, md = live && !hv && end - beg > FM_LIGHT;
     const uint64_t hm = __ballot(hv), mm = __ballot(md);
     uint32_t hb = 0, mb = 0;
     if (lane_id() == 0) {
@@ -682,10 +682,15 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
                            (uint4 *)blocks.p);
         KCHECK(hipGetLastError());
     }
-    uint32_t fm_light = FM_LIGHT_DEFAULT;
+    uint32_t fm_heavy = FM_HEAVY; // (KISS_HIP_FM_HEAVY: tuning hook, 16 .. 65536)
+    if (const char *e = getenv("KISS_HIP_FM_HEAVY")) {
+        const int v = atoi(e);
+        if (v >= 16 && v <= 65536) fm_heavy = (uint32_t)v;
+    }
+    uint32_t fm_light = fm_heavy;
     if (const char *e = getenv("KISS_HIP_FM_LIGHT")) {
         const int v = atoi(e);
-        if (v >= 1 && v <= (int)FM_HEAVY) fm_light = (uint32_t)v;
+        if (v >= 1 && v <= (int)fm_heavy) fm_light = (uint32_t)v;
     }
     KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
@@ -705,7 +710,7 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
         if (timed) (void)hipEventRecord(sev[0], ctx->stream);
         hipLaunchKernelGGL(k_fm_range, dim3(grid), dim3(FM_THREADS), 0, ctx->stream, f, patterns, L, Q, beg, end,
                            (uint64_t *)cap.p, (uint64_t *)fcap.p, (uint32_t *)heavy.p + 1, (uint32_t *)heavy.p,
-                           (uint32_t *)medium.p + 1, (uint32_t *)medium.p, fm_light);
+                           (uint32_t *)medium.p + 1, (uint32_t *)medium.p, fm_light, fm_heavy);
         if (timed) (void)hipEventRecord(sev[1], ctx->stream);
         KCHECK(hipGetLastError());
     }

@@ -468,7 +468,12 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
     DstPos dp;
     for (int c = 0; c < 4; c++) dp.p[c] = sw.pos[c];
     ctx->stats.induce_passes++;
-    if (N <= SMALL_MAX) {
+    uint64_t small_max = SMALL_MAX;
+    if (const char *e = getenv("KISS_HIP_INDUCE_SMALL_MAX")) { // tuning hook
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 64 && v <= (1ull << 20)) small_max = v;
+    }
+    if (N <= small_max) {
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
             if (remap)

@@ -200,6 +200,10 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // kiss_lms_sort in exact mode gives up (no output) once suffixes still tie after this many bases
 constexpr uint64_t KISS_EXACT_MSD_MAX_DEPTH = 32768;
 constexpr int KISS_INTERNAL_TOO_DEEP = 1000; // never crosses the ABI
+// Order of the bounded phase in front of the rank doubling (PREFIX_DOUBLING at k >= n, and the fall-back of exact order on
+// very deep ties).  Round 3 sweep at chm13 size, whole exact sort: h0 = 128 / 256 / 512 / 1024 -> 224 / 211 / 205 / 213 ms
+// (a deeper bounded phase costs pivot-round work, a shallower one leaves more tied suffixes to the doubling rounds).
+constexpr uint32_t KISS_EXACT_H0 = 512;
 // exact order from an h0-ordered SA by rank doubling over the full suffix array (lms_sort.hip)
 int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, uint8_t *heads_in = nullptr);
 // isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)

@@ -29,7 +29,7 @@ namespace {
 
 constexpr int MG_HIST_BITS = 14; // 7 bases: 16 384 bins split <= 64 key ranges finely enough; private LDS histograms
 constexpr int MG_MAX_DEV = 64;
-constexpr uint32_t MG_EXACT_H0 = 256;
+constexpr uint32_t MG_EXACT_H0 = KISS_EXACT_H0;
 
 struct Barrier {
     std::mutex mu;

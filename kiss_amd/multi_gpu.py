@@ -26,7 +26,7 @@ from . import _lib
 from .sorter import _check
 
 HIST_BITS = 14   # 7 bases: the histogram is private to a workgroup in LDS (64 KiB), 16 384 bins split <= 64 key ranges finely enough
-EXACT_H0 = 256  # bounded order of the first phase when exact order falls back to rank doubling
+EXACT_H0 = 512  # bounded order of the first phase when exact order falls back to rank doubling (KISS_EXACT_H0 of the library)
 NEAR_INLINE = 1024  # near-end positions that ride in the fused all-gather (k = 256: about a hundred; more: one extra gather)
 
 

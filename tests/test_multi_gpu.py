@@ -154,8 +154,9 @@ class DeepTieBackend(OracleBackend):
         return super().sort(keys, pos)
 
     def refine_exact(self, SA, h0):
-        assert h0 == 256 and dist.get_rank() == 0
-        want = self.orc.suffix_sort(self.S, 256)  # the rerun delivered the 256-ordered SA
+        from kiss_amd import multi_gpu
+        assert h0 == multi_gpu.EXACT_H0 and dist.get_rank() == 0
+        want = self.orc.suffix_sort(self.S, h0)  # the rerun delivered the h0-ordered SA
         assert np.array_equal(SA.numpy().view(np.uint32), want)
         self.refined += 1
         return torch.from_numpy(self.orc.suffix_sort(self.S, 0xFFFFFFFF).view(np.int32).copy())

@@ -5,6 +5,7 @@ import pytest
 from tests import gen
 
 pytestmark = pytest.mark.gpu
+EXACT_H0 = 512  # order of the bounded phase in front of the rank doubling (KISS_EXACT_H0, kiss_internal.hpp)
 
 
 @pytest.fixture(scope="module")
@@ -156,7 +157,7 @@ def test_prefix_doubling_exact(ctx, oracle, shape):
         base = gen.iid(n // 2, 8)
         S = np.concatenate([base, gen.iid(100, 9), base[:n // 2 - 100 - 37]])
     st = _exact_by_doubling(ctx, oracle, S)
-    assert st["refine_depth"] == 256
+    assert st["refine_depth"] == EXACT_H0
     # (period1, a text of one base, has no LMS suffix at all: the induction yields the exact order by itself, nothing is
     #  tainted and the doubling phase finds nothing to do)
     if shape in ("period2", "period7", "period400", "period5000", "nested", "tail_repeat"):
@@ -202,7 +203,7 @@ def test_exact_msd_falls_back_to_doubling(ctx, oracle):
     S = np.tile(np.array([0, 2, 1, 3, 3, 0, 1], np.uint8), n // 7 + 1)[:n]
     sa = ctx.suffix_sort(S, kiss_amd.K_UNBOUNDED, algo=0)
     st = ctx.stats()
-    assert st["refine_depth"] == 256 and st["doubling_rounds"] >= 1
+    assert st["refine_depth"] == EXACT_H0 and st["doubling_rounds"] >= 1
     assert np.array_equal(sa, oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED))
     # a repeat shorter than the switch-over depth stays on the 32-bases-per-round path
     S2 = gen.iid(n, 31)
