@@ -547,7 +547,7 @@ int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, ui
         const uint64_t words = max_n / 32 + 8;
         ctx->pk_words = words;
         ctx->n_tiles_cap = words / 256 + 2;
-        ctx->ind_tiles_cap = 4 * ((max_n + 1) / 2048 + 2) + 2;
+        ctx->ind_tiles_cap = 4 * ((max_n + 1) / 1024 + 2) + 2; // (room for partition tiles down to 1024 items)
 #define ALLOC(p, cnt) if ((rc = dmalloc(ctx, &ctx->p, (cnt)))) break
         ALLOC(pk, words);
         ALLOC(tile_gp, ctx->n_tiles_cap);

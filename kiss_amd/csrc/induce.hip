@@ -26,7 +26,10 @@
 namespace {
 
 constexpr int IN_THREADS = 256;
-constexpr int IN_ITEMS = 8;
+#ifndef KISS_IN_ITEMS
+#define KISS_IN_ITEMS 8 // (items per thread of the partition passes; -DKISS_IN_ITEMS=4 / 16: the tile-size A-B of round 3)
+#endif
+constexpr int IN_ITEMS = KISS_IN_ITEMS;
 constexpr int IN_WAVES = IN_THREADS / 64;
 constexpr int IN_TILE = IN_THREADS * IN_ITEMS;   // 2048
 constexpr int SM_THREADS = 1024;
