@@ -12,6 +12,7 @@
 // Used by the PREFIX_DOUBLING refinement (lms_sort.hip: kiss_exact_refine).
 #include "kiss_internal.hpp"
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -29,7 +30,11 @@ template <bool FROM_SA>
 __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__restrict__ SA,
                                                              const uint64_t *__restrict__ pairs_in, uint64_t base,
                                                              uint64_t count, int shift, int bin_shift,
-                                                             uint32_t *__restrict__ cursor, uint64_t *__restrict__ out)
+                                                             uint32_t *__restrict__ cursor, uint64_t *__restrict__ out,
+                                                             int idx_shift, // FROM_SA: the pair's index is SA[i] >> idx_shift
+                                                             const uint32_t *__restrict__ binbase, uint32_t bstride)
+// binbase (optional): bins of unequal, known size -- bin d starts at out + binbase[d * bstride] - binbase[0]
+// (the sparse form, kiss_rank_build_lms: not every index has an entry) instead of at out + (d << bin_shift)
 {
     __shared__ uint64_t stage[IB_TILE];
     __shared__ uint32_t lcnt[256];  // items of this tile per bin
@@ -50,10 +55,10 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
 #pragma unroll
             for (int q = 0; q < IB_ITEMS / 4; q++) {
                 const uint4 t = *reinterpret_cast<const uint4 *>(SA + base + g0 + 4 * q);
-                pr[4 * q] = ((uint64_t)t.x << 32) | (base + g0 + 4 * q);
-                pr[4 * q + 1] = ((uint64_t)t.y << 32) | (base + g0 + 4 * q + 1);
-                pr[4 * q + 2] = ((uint64_t)t.z << 32) | (base + g0 + 4 * q + 2);
-                pr[4 * q + 3] = ((uint64_t)t.w << 32) | (base + g0 + 4 * q + 3);
+                pr[4 * q] = ((uint64_t)(t.x >> idx_shift) << 32) | (base + g0 + 4 * q);
+                pr[4 * q + 1] = ((uint64_t)(t.y >> idx_shift) << 32) | (base + g0 + 4 * q + 1);
+                pr[4 * q + 2] = ((uint64_t)(t.z >> idx_shift) << 32) | (base + g0 + 4 * q + 2);
+                pr[4 * q + 3] = ((uint64_t)(t.w >> idx_shift) << 32) | (base + g0 + 4 * q + 3);
             }
         } else {
 #pragma unroll
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
             const uint32_t li = l0 + (uint32_t)j;
             if (li < tile_count) {
                 const uint64_t g = tile_base + li;
-                pr[j] = FROM_SA ? (((uint64_t)SA[base + g] << 32) | (base + g)) : pairs_in[g];
+                pr[j] = FROM_SA ? (((uint64_t)(SA[base + g] >> idx_shift) << 32) | (base + g)) : pairs_in[g];
             } else
                 pr[j] = 0;
         }
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
         if (idx < tile_count) {
             const uint64_t v = stage[idx];
             const uint32_t d = (uint32_t)(v >> (32 + shift)) & 255u;
-            out[((uint64_t)d << bin_shift) + gpos[d] + (idx - loff[d])] = v;
+            const uint64_t bin0 = binbase ? (uint64_t)(binbase[d * bstride] - binbase[0]) : ((uint64_t)d << bin_shift);
+            out[bin0 + gpos[d] + (idx - loff[d])] = v;
         }
     }
 }
@@ -192,7 +198,7 @@ int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32
     {
         KTimer t(ctx, KISS_HIP_K_ISA, total);
         hipLaunchKernelGGL((k_isa_partition<true>), dim3((unsigned)div_up(total, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
-                           SA, nullptr, 0ull, total, L1_SHIFT, L1_SHIFT, cursor, ctx->pairs1);
+                           SA, nullptr, 0ull, total, L1_SHIFT, L1_SHIFT, cursor, ctx->pairs1, 0, nullptr, 0u);
         KCHECK(hipGetLastError());
     }
     KTimer t(ctx, KISS_HIP_K_ISA, total);
@@ -201,7 +207,8 @@ int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32
         const uint64_t cnt = total - lo < (1ull << L1_SHIFT) ? total - lo : (1ull << L1_SHIFT);
         KTRY(kiss_zero_u32(ctx, cursor + 256 * CUR_STRIDE, 256 * CUR_STRIDE));
         hipLaunchKernelGGL((k_isa_partition<false>), dim3((unsigned)div_up(cnt, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
-                           nullptr, ctx->pairs1 + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + 256 * CUR_STRIDE, ctx->pairs2);
+                           nullptr, ctx->pairs1 + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + 256 * CUR_STRIDE, ctx->pairs2, 0,
+                           nullptr, 0u);
         // pairs2 is bin-major with 2^16-pair bins; in a short last bin the sub-bins are not full: write bin by bin
         if (cnt == (1ull << L1_SHIFT)) {
             hipLaunchKernelGGL(k_isa_write, dim3((unsigned)div_up(cnt, 256)), dim3(256), 0, ctx->stream, ctx->pairs2, cnt,
@@ -213,6 +220,86 @@ int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32
                                    ctx->pairs2 + (s << L2_SHIFT), c2, isa);
             }
         }
+        KCHECK(hipGetLastError());
+    }
+    return KISS_HIP_OK;
+}
+
+// ---- the sparse form: rank[L[i] >> 1] = i for the m LMS positions in L (no two LMS positions are neighbours, so
+// position >> 1 is a collision-free index: half the array of a full inverse).  Not every index has an entry, so the bin
+// sizes are not the bin widths -- but the ascending LMS list says how many positions fall below any bound: one binary
+// search per 2^16-index sub-bin gives the table both partition levels take their bin starts from.
+namespace {
+__global__ __launch_bounds__(256) void k_lms_bounds(const uint32_t *__restrict__ lms_asc, uint64_t m, uint32_t entries,
+                                                    uint32_t *__restrict__ bt)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= entries) return;
+    const uint64_t bound = (uint64_t)j << (L2_SHIFT + 1); // positions below it have index < j * 2^16
+    uint64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)lms_asc[mid] < bound) lo = mid + 1;
+        else hi = mid;
+    }
+    bt[j] = (uint32_t)lo;
+}
+__global__ __launch_bounds__(256) void k_rank_direct(const uint32_t *__restrict__ L, uint64_t count,
+                                                     uint32_t *__restrict__ rank)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) rank[L[i] >> 1] = (uint32_t)i;
+}
+} // namespace
+
+// L: the m LMS positions in sorted order; lms_asc: the same positions ascending.  rank: (n >> 1) + 1 words.
+// pairs1: m u64 of scratch; pairs2: min(m, 2^24) u64; small: 65536 + 2 u32 (bin cursors and the bounds table).
+int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lms_asc, uint64_t m, uint64_t n,
+                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small)
+{
+    if (m == 0) return KISS_HIP_OK;
+    uint64_t direct_max = 1ull << 25;
+    if (const char *e = getenv("KISS_HIP_ISA_DIRECT_MAX")) direct_max = strtoull(e, nullptr, 10); // test hook
+    if (m <= direct_max || m < (1ull << 16)) {
+        KTimer t(ctx, KISS_HIP_K_ISA, m);
+        hipLaunchKernelGGL(k_rank_direct, dim3((unsigned)div_up(m, 256)), dim3(256), 0, ctx->stream, L, m, rank);
+        KCHECK(hipGetLastError());
+        return KISS_HIP_OK;
+    }
+    const uint64_t idx_total = (n >> 1) + 1;
+    const uint64_t bins = div_up(idx_total, 1ull << L1_SHIFT);
+    if (bins > 128) return KINTERNAL();
+    const uint32_t sub_total = (uint32_t)(bins * 256);
+    uint32_t *cursor = small;                     // 2 x 256 strided cursors
+    uint32_t *bt = small + 512 * CUR_STRIDE;      // sub_total + 1 entries
+    {
+        KTimer t(ctx, KISS_HIP_K_ISA, m);
+        hipLaunchKernelGGL(k_lms_bounds, dim3((unsigned)div_up(sub_total + 1, 256)), dim3(256), 0, ctx->stream, lms_asc, m,
+                           sub_total + 1, bt);
+        KCHECK(hipGetLastError());
+    }
+    std::vector<uint32_t> h_bt(sub_total + 1);
+    KCHECK(hipMemcpyAsync(h_bt.data(), bt, (sub_total + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    KCHECK(hipStreamSynchronize(ctx->stream));
+    if (h_bt[sub_total] != m) return KINTERNAL();
+    KTRY(kiss_zero_u32(ctx, cursor, 256 * CUR_STRIDE));
+    {
+        KTimer t(ctx, KISS_HIP_K_ISA, m);
+        hipLaunchKernelGGL((k_isa_partition<true>), dim3((unsigned)div_up(m, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream, L,
+                           nullptr, 0ull, m, L1_SHIFT, L1_SHIFT, cursor, pairs1, 1, bt, 256u);
+        KCHECK(hipGetLastError());
+    }
+    KTimer t(ctx, KISS_HIP_K_ISA, m);
+    for (uint64_t b = 0; b < bins; b++) {
+        const uint64_t lo = h_bt[256 * b], cnt = h_bt[256 * (b + 1)] - lo;
+        if (cnt == 0) continue;
+        if (cnt > (1ull << L1_SHIFT)) return KINTERNAL();
+        KTRY(kiss_zero_u32(ctx, cursor + 256 * CUR_STRIDE, 256 * CUR_STRIDE));
+        hipLaunchKernelGGL((k_isa_partition<false>), dim3((unsigned)div_up(cnt, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
+                           nullptr, pairs1 + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + 256 * CUR_STRIDE, pairs2, 0,
+                           bt + 256 * b, 1u);
+        // sub-bin after sub-bin: the writes of one stay inside a 256 KiB window of the rank array
+        hipLaunchKernelGGL(k_isa_write, dim3((unsigned)div_up(cnt, 256)), dim3(256), 0, ctx->stream, pairs2, cnt, rank);
         KCHECK(hipGetLastError());
     }
     return KISS_HIP_OK;

@@ -208,6 +208,14 @@ constexpr uint32_t KISS_EXACT_H0 = 512;
 int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA, uint8_t *heads_in = nullptr);
 // isa[SA[i]] = i for a permutation SA of [0, total) (isa.hip)
 int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
+// rank[L[i] >> 1] = i for the m LMS positions of L (lms_asc: the same positions ascending); scratch from the caller (isa.hip)
+int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lms_asc, uint64_t m, uint64_t n,
+                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small);
+// Exact order of the LMS suffixes BEFORE the induction (lms_sort.hip): the merged h0-ordered list ctx->lmsP / ctx->lmsC is
+// refined by rank doubling over the LMS suffixes alone.  `scratch`: the (n + 1)-word suffix array buffer (not yet written).
+// *resolved = false: the list is as kiss_merge_lms left it (still h0-ordered, taint bits intact) and kiss_exact_refine has
+// to finish the job on the suffix array.
+int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *scratch, bool *resolved);
 // fills ctx->lmsP / ctx->lmsC from the far list and the near-end ranks of the last kiss_place_lms
 int kiss_merge_lms(kiss_hip_ctx *ctx);
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC

@@ -578,8 +578,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ isa,
                                                           uint32_t *__restrict__ octx,
                                                           uint32_t *__restrict__ tmark, // taint marks of retiring items
-                                                          const uint64_t *__restrict__ payload) // optional, with tmark: words
+                                                          const uint64_t *__restrict__ payload, // optional, with tmark: words
                                                           // whose low KISS_KEY_CTX bits are the items' context words
+                                                          int isa_shift) // isa is indexed by position >> isa_shift
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             if (tmark && payload) // the word came along with the sort key (k_pivot_lcp)
                 tmark[sl] = (uint32_t)(payload[i] & KISS_KEY_CTX_MASK) | (((tl >> j) & 1u) ? KISS_CTX_TAINT : 0u);
             else if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
-            if (isa) isa[p] = sl;
+            if (isa) isa[p >> isa_shift] = sl;
             if constexpr (SRC != FC_HEADS) {
                 if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
             }
@@ -1101,7 +1102,7 @@ template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
                uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr, uint32_t *nctx = nullptr,
-               bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr)
+               bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr, int isa_shift = 0)
 {
     if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
@@ -1119,7 +1120,7 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     else // (without slots an item's slot is its index: out == pos means the list is in place already)
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
-                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload);
+                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload, isa_shift);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -1520,19 +1521,20 @@ namespace {
 // its own -- no text is read for it (at chm13 size 94 % of the 3.1 G entries; this kernel was 69 ms of random reads).
 __global__ __launch_bounds__(LS_THREADS) void k_group_heads(const uint64_t *__restrict__ pk, uint64_t n,
                                                            const uint32_t *__restrict__ SA, uint64_t count, uint32_t h0,
-                                                           const uint32_t *__restrict__ cw, uint8_t *__restrict__ heads)
+                                                           const uint32_t *__restrict__ cw, uint8_t *__restrict__ heads,
+                                                           uint32_t lo) // first entry that can be tied (SA: 1, SA[0] = n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     const bool valid = i < count;
     const uint64_t p = valid ? SA[i] : 0;
-    const bool tainted = valid && i > 0 && (!cw || (cw[i] & KISS_CTX_TAINT) != 0); // SA[0] = n has no context word
+    const bool tainted = valid && i >= lo && (!cw || (cw[i] & KISS_CTX_TAINT) != 0); // SA[0] = n has no context word
     const bool pfull = tainted && p + h0 <= n;
     const uint64_t kp = pfull ? kiss_key32(pk, p) : 0ull; // h0 >= 32
     // predecessor's first word: from the neighbouring lane, lane 0 loads it
     uint64_t q = __shfl_up(p, 1, 64);
     uint64_t kq = __shfl_up(kp, 1, 64);
     bool qfull = __shfl_up((int)pfull, 1, 64) != 0;
-    if (lane_id() == 0 && pfull && i > 1) {
+    if (lane_id() == 0 && pfull && i > lo) {
         q = SA[i - 1];
         qfull = q + h0 <= n && (!cw || (cw[i - 1] & KISS_CTX_TAINT) != 0);
         kq = qfull ? kiss_key32(pk, q) : 0ull;
@@ -1585,7 +1587,8 @@ constexpr int GH_REGIONS = 256;
 __global__ __launch_bounds__(GH_THREADS) void k_heads_candidates(const uint32_t *__restrict__ SA, uint64_t count, uint64_t n,
                                                                 uint32_t h0, const uint32_t *__restrict__ cw,
                                                                 uint8_t *__restrict__ heads, uint32_t *__restrict__ list,
-                                                                uint64_t region_cap, uint32_t *__restrict__ ncand)
+                                                                uint64_t region_cap, uint32_t *__restrict__ ncand,
+                                                                uint32_t lo) // first entry that can be tied (SA: 1)
 {
     __shared__ uint32_t wcount[GH_THREADS / 64];
     __shared__ uint32_t s_base;
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__(GH_THREADS) void k_heads_candidates(const uint32_t 
     const uint64_t i = (uint64_t)blockIdx.x * GH_THREADS + threadIdx.x;
     bool cand = false;
     if (i < count) {
-        if (i > 1 && (cw[i] & KISS_CTX_TAINT) && (cw[i - 1] & KISS_CTX_TAINT)) {
+        if (i > lo && (cw[i] & KISS_CTX_TAINT) && (cw[i - 1] & KISS_CTX_TAINT)) {
             const uint64_t p = SA[i], q = SA[i - 1];
             cand = p + h0 <= n && q + h0 <= n;
         }
@@ -1670,14 +1673,15 @@ __global__ __launch_bounds__(LS_THREADS) void k_isa_update(const uint32_t *__res
                                                           const uint32_t *__restrict__ slot,
                                                           const uint32_t *__restrict__ seg,
                                                           const uint32_t *__restrict__ segstart, uint64_t count,
-                                                          uint32_t *__restrict__ isa, uint32_t *__restrict__ maxlen)
+                                                          uint32_t *__restrict__ isa, uint32_t *__restrict__ maxlen,
+                                                          int shift) // isa is indexed by position >> shift
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     uint32_t len = 0;
     if (i < count) {
         const uint32_t sg = seg[i];
         const uint32_t a = segstart[sg];
-        isa[pos[i]] = slot[a];
+        isa[pos[i] >> shift] = slot[a];
         if ((uint32_t)i == a) len = segstart[sg + 1] - a;
     }
 #pragma unroll
@@ -1777,7 +1781,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
                 KTRY(kiss_zero_u32(ctx, d_nc, GH_REGIONS));
                 hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(total, GH_THREADS)), dim3(GH_THREADS), 0,
-                                   ctx->stream, d_SA, total, n, h0, ctx->CTX, heads, ctx->posA, region_cap, d_nc);
+                                   ctx->stream, d_SA, total, n, h0, ctx->CTX, heads, ctx->posA, region_cap, d_nc, 1u);
                 uint32_t h_nc[GH_REGIONS];
                 KCHECK(hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream));
                 KCHECK(hipStreamSynchronize(ctx->stream));
@@ -1793,7 +1797,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             if (!done)
                 hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, ctx->pk, n, d_SA,
                                    total, h0, (no_taint || !ctx->ctx_words_valid) ? (const uint32_t *)nullptr : ctx->CTX,
-                                   heads);
+                                   heads, 1u);
         }
         uint64_t tot;
         if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, total, 0, 0, d_total))) break;
@@ -1829,7 +1833,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
             KTimer t(ctx, KISS_HIP_K_ISA, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, d_maxlen);
             hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS, count,
-                               isa, d_maxlen);
+                               isa, d_maxlen, 0);
         }
         uint64_t h = h0;
         while (count > 0) {
@@ -1902,7 +1906,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 KTimer t(ctx, KISS_HIP_K_ISA, count);
                 hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, d_maxlen);
                 hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS,
-                                   count, isa, d_maxlen);
+                                   count, isa, d_maxlen, 0);
             }
             h *= 2;
         }
@@ -1914,4 +1918,420 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     }
 
     return rc;
+}
+
+// =====================================================================================================================
+// Exact order at the LMS level (round 3): the doubling runs BEFORE the induction, over the LMS suffixes alone.
+//
+// The reference's KISS2 does the same thing in its own way (`kiss2_core.hpp:835-886`: exact order of the LMS suffixes by
+// prefix doubling over an encoded LMS string, then ONE induction).  Here the h0-ordered merged LMS list L (ctx->lmsP, all
+// m LMS suffixes, ties in position order, the tied ones tainted) is refined in place:
+//   * rank[p >> 1] = slot of p in L (LMS positions are never neighbours, so p >> 1 is collision-free; tied suffixes carry the
+//     slot of their group's first member) -- a third of the entries of a full inverse suffix array, and the m-entry list is
+//     what the tie detection, the compaction and the rounds stream instead of the n + 1 entries of SA;
+//   * a round: all groups share >= D bases.  The members of a group share the LMS positions inside their common window
+//     too, so a group picks the last position x = p + d, d < D, that the window alone proves to be an LMS position
+//     (k_lms_stride: a type needs a differing base to its right, inside the window), and its members sort on
+//     rank[(p + d) >> 1]: equal keys = equal through d + D bases.  The next round's D is D + the smallest stride.
+//   * a group whose window ends in >= D/2 bases without such a position (a long run of one base, mostly) is "stuck": its
+//     members (<= LX_STUCK_MAX) are ordered by comparing the text directly, which is final.
+// Anything unexpected -- a stuck group of more members, comparisons that run past LX_STUCK_STEPS steps for one member,
+// a rank that was never written -- aborts: the list is merged again as it was and kiss_exact_refine finishes the job on
+// the suffix array as before (texts like A^1000 C repeated: their LMS suffixes are further apart than any window).
+namespace {
+
+constexpr uint32_t LX_STUCK_STEPS = 1u << 18; // all comparisons of one member of a stuck group together, <= 128 bases per step
+constexpr uint32_t LX_STUCK_MAX = 8192;       // members of a stuck group (each is compared with all the others)
+enum { LX_MAXLEN = 0, LX_MIN_D = 1, LX_ABORT = 2, LX_STUCK = 3 };
+
+__global__ void k_lx_ctl_init(uint32_t *__restrict__ ctl)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl[LX_MIN_D] = 0xFFFFFFFFu;
+        ctl[LX_ABORT] = 0;
+        ctl[LX_STUCK] = 0;
+    }
+}
+
+// suffix pi < suffix pj, both known to be equal on their first d bases (pi + d, pj + d <= n); the suffix that runs
+// off the text first is the smaller one (the sentinel)
+__device__ __forceinline__ bool exact_less(const uint64_t *__restrict__ pk, uint64_t n, uint64_t pi, uint64_t pj, uint64_t d,
+                                           uint32_t &steps_left, bool *gave_up)
+{
+    for (; steps_left; steps_left--) {
+        const uint64_t qi = pi + d, qj = pj + d;
+        const uint64_t ri = n - qi, rj = n - qj; // bases left
+        if (ri >= 160 && rj >= 160) {
+            const uint64_t *wi = pk + (qi >> 5), *wj = pk + (qj >> 5);
+            const uint32_t si = 2u * (uint32_t)(qi & 31u), sj = 2u * (uint32_t)(qj & 31u);
+            uint64_t a[5], b[5];
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                a[t] = wi[t];
+                b[t] = wj[t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));
+                const uint64_t kj = (b[t] << sj) | ((b[t + 1] >> 1) >> (63u - sj));
+                if (ki != kj) return ki < kj;
+            }
+            d += 128;
+            continue;
+        }
+        uint64_t len = ri < rj ? ri : rj;
+        if (len > 32) len = 32;
+        uint64_t ki = kiss_key32(pk, qi), kj = kiss_key32(pk, qj);
+        if (len < 32) {
+            const uint64_t mask = len ? ~0ull << (64 - 2 * len) : 0ull;
+            ki &= mask;
+            kj &= mask;
+        }
+        if (ki != kj) return ki < kj;
+        if (len < 32) return ri < rj; // one of them ends here
+        d += 32;
+    }
+    *gave_up = true;
+    return false;
+}
+
+// One thread per group: the stride d (0 = stuck).  Scans the window [p0, p0 + D) of the group's first member from its
+// right end, at most scan_cap bases: position y + 1 is an LMS position if base(y) > base(y + 1) and y + 1 is S-type, and
+// a type is only known once a differing base has been seen to the right.
+__global__ __launch_bounds__(LS_THREADS) void k_lms_stride(const uint64_t *__restrict__ pk, uint64_t n,
+                                                          const uint32_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ segstart, uint64_t nseg, uint64_t D,
+                                                          uint64_t scan_cap, uint32_t *__restrict__ dG,
+                                                          uint32_t *__restrict__ ctl)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    uint32_t d = 0;
+    const bool valid = g < nseg;
+    if (valid) {
+        const uint64_t p0 = pos[segstart[g]];
+        if (p0 + D <= n) {
+            uint64_t e = p0 + D; // bases [ylo, e) are still to be looked at
+            const uint64_t ylo = (D - 1 > scan_cap) ? (e - 1 - scan_cap) : p0;
+            int t = 0; // type of the base right of the current one: 0 unknown, 1 S, 2 L
+            uint32_t cn = 0;
+            bool first = true;
+            while (e > ylo && d == 0) {
+                const uint64_t s = (e - ylo > 32) ? e - 32 : ylo;
+                const uint64_t w = kiss_key32(pk, s);
+                int j = (int)(e - s) - 1;
+                if (first) {
+                    cn = (uint32_t)(w >> (62 - 2 * j)) & 3u;
+                    j--;
+                    first = false;
+                }
+                for (; j >= 0; j--) {
+                    const uint32_t c = (uint32_t)(w >> (62 - 2 * j)) & 3u;
+                    if (c > cn) {
+                        if (t == 1) {
+                            d = (uint32_t)(s + (uint64_t)j + 1 - p0);
+                            break;
+                        }
+                        t = 2;
+                    } else if (c < cn) {
+                        t = 1;
+                    }
+                    cn = c;
+                }
+                e = s;
+            }
+        } else {
+            atomicOr(&ctl[LX_ABORT], 8u); // a tied suffix without D bases: cannot be
+        }
+        dG[g] = d;
+    }
+    // smallest stride of the round (one atomic per wave, and only while it still lowers the minimum)
+    uint32_t md = (valid && d) ? d : 0xFFFFFFFFu;
+#pragma unroll
+    for (int x = 32; x >= 1; x >>= 1) {
+        const uint32_t o = __shfl_xor(md, x, 64);
+        md = o < md ? o : md;
+    }
+    const uint64_t stuck = __ballot(valid && d == 0);
+    if (lane_id() == 0) {
+        if (md != 0xFFFFFFFFu && md < __hip_atomic_load(&ctl[LX_MIN_D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(&ctl[LX_MIN_D], md);
+        if (stuck) atomicAdd(&ctl[LX_STUCK], (uint32_t)__popcll(stuck));
+    }
+}
+
+__global__ __launch_bounds__(LS_THREADS) void k_gather_ranks_lms(const uint32_t *__restrict__ rank,
+                                                                const uint32_t *__restrict__ pos,
+                                                                const uint32_t *__restrict__ seg,
+                                                                const uint32_t *__restrict__ dG, uint64_t count, uint64_t n,
+                                                                uint64_t *__restrict__ key, uint32_t *__restrict__ ctl)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t d = dG[seg[i]];
+    uint64_t k = 0;
+    if (d) {
+        const uint64_t q = (uint64_t)pos[i] + d;
+        const uint32_t r = q < n ? rank[q >> 1] : 0xFFFFFFFFu;
+        if (r == 0xFFFFFFFFu) atomicOr(&ctl[LX_ABORT], 1u); // not an LMS position after all: cannot be
+        k = (uint64_t)r << 32;
+    }
+    key[i] = k;
+}
+
+// k_group_sort_small for the LMS rounds: a stuck group orders itself by comparing the text from base D on
+__global__ __launch_bounds__(LS_THREADS) void k_group_sort_small_lms(const uint64_t *__restrict__ pk, uint64_t n,
+                                                                    const uint64_t *__restrict__ key,
+                                                                    const uint32_t *__restrict__ pos,
+                                                                    const uint32_t *__restrict__ seg,
+                                                                    const uint32_t *__restrict__ segstart,
+                                                                    const uint32_t *__restrict__ dG, uint64_t count,
+                                                                    uint64_t D, uint64_t *__restrict__ okey,
+                                                                    uint32_t *__restrict__ opos, uint64_t *__restrict__ big,
+                                                                    uint32_t *__restrict__ ctl)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t sg = seg[i];
+    const uint32_t a = segstart[sg], b = segstart[sg + 1];
+    const bool stuck = dG[sg] == 0;
+    const bool isbig = !stuck && b - a > SMALL_SEG; // (a stuck group is not sorted on keys, whatever its size)
+    if (big) big[i] = isbig ? ((1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u)) : 0ull;
+    if (isbig) return;
+    if (stuck && b - a > LX_STUCK_MAX) { // left where it is (the abort undoes the round anyway)
+        if ((uint32_t)i == a) atomicOr(&ctl[LX_ABORT], 2u);
+        okey[i] = 0;
+        opos[i] = pos[i];
+        return;
+    }
+    uint32_t r = 0;
+    uint64_t ko;
+    if (!stuck) {
+        const uint64_t ki = key[i];
+        for (uint32_t j = a; j < b; j++) {
+            const uint64_t kj = key[j];
+            r += (kj < ki || (kj == ki && j < (uint32_t)i)) ? 1u : 0u;
+        }
+        ko = ki;
+    } else {
+        const uint64_t pi = pos[i];
+        bool gave_up = false;
+        uint32_t steps_left = LX_STUCK_STEPS;
+        for (uint32_t j = a; j < b; j++)
+            if (j != (uint32_t)i) r += exact_less(pk, n, pos[j], pi, D, steps_left, &gave_up) ? 1u : 0u;
+        if (gave_up) atomicOr(&ctl[LX_ABORT], 4u);
+        ko = (uint64_t)r << 32; // all different: every member retires
+    }
+    okey[a + r] = ko;
+    opos[a + r] = pos[i];
+}
+
+// the context words of the suffixes that may have moved (the tainted ones): gathered again, taint cleared
+__global__ __launch_bounds__(LS_THREADS) void k_lms_ctx_fix(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ L,
+                                                           uint32_t *__restrict__ C, uint64_t m)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
+    if (i >= m) return;
+    if (C[i] & KISS_CTX_TAINT) C[i] = kiss_load_ctx(pk, L[i]);
+}
+
+} // namespace
+
+int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *scratch, bool *resolved)
+{
+    *resolved = false;
+    if (h0 < 32 || n < h0 || !scratch) return KINTERNAL();
+    KTRY(kiss_merge_lms(ctx));
+    const uint64_t m = ctx->m;
+    const unsigned T = LS_THREADS;
+    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    if (m < 2) {
+        *resolved = true;
+        return KISS_HIP_OK;
+    }
+    KTRY(kiss_need_ctx_words(ctx));
+    ctx->ctx_words_valid = false;
+    uint32_t *L = ctx->lmsP, *C = ctx->lmsC;
+    // CTX (n + 2 words, not in use before the induction): the rank array, then one tie flag byte per list entry
+    uint32_t *R = ctx->CTX;
+    const uint64_t r_words = (n >> 1) + 1;
+    uint8_t *heads = reinterpret_cast<uint8_t *>(ctx->CTX + ((r_words + 3) & ~3ull));
+    if (((r_words + 3) & ~3ull) + (m + 16) / 4 + 1 > ctx->max_n + 2) return KINTERNAL();
+    uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
+    uint32_t *ctl = ctx->d_small + 8;
+    uint64_t *pairs1 = reinterpret_cast<uint64_t *>(((uintptr_t)scratch + 7) & ~(uintptr_t)7);
+    uint32_t *bigpos0 = scratch, *bigpos1 = scratch + m; // (after the rank array is built: pairs1 is dead then)
+
+    int rc = KISS_HIP_OK;
+    bool aborted = false;
+    uint32_t why = 0;
+    const uint64_t rounds_before = ctx->stats.doubling_rounds, item_rounds_before = ctx->stats.sort_item_rounds;
+    do {
+        { // tie flags: both neighbours tainted and equal on their first h0 bases
+            KTimer t(ctx, KISS_HIP_K_GROUP_HEADS, m);
+            uint32_t *d_nc = ctx->rx_ghist;
+            const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
+            if ((rc = kiss_zero_u32(ctx, d_nc, GH_REGIONS))) break;
+            hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(m, GH_THREADS)), dim3(GH_THREADS), 0, ctx->stream, L, m, n,
+                               h0, C, heads, ctx->posA, region_cap, d_nc, 0u);
+            uint32_t h_nc[GH_REGIONS];
+            if (hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = KISS_HIP_E_HIP;
+                break;
+            }
+            uint32_t mx = 0;
+            for (uint32_t v : h_nc) mx = v > mx ? v : mx;
+            if (mx <= region_cap) {
+                if (mx)
+                    hipLaunchKernelGGL(k_heads_compare, dim3((unsigned)div_up((uint64_t)mx, T), GH_REGIONS), dim3(T), 0, ctx->stream,
+                                       ctx->pk, L, ctx->posA, region_cap, d_nc, h0, heads);
+            } else {
+                hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(m, T)), dim3(T), 0, ctx->stream, ctx->pk, n, L, m, h0, C,
+                                   heads, 0u);
+            }
+        }
+        uint64_t tot;
+        if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, m, 0, 0, d_total))) break;
+        if ((rc = fc_read_total(ctx, d_total, &tot))) break;
+        uint64_t count = tot >> 32, nseg = tot & 0xFFFFFFFFull;
+        ctx->stats.refine_items = count;
+        if (dbg)
+            fprintf(stderr, "[kiss_hip] lms refine: %llu of %llu LMS suffixes tied at depth %u in %llu groups\n",
+                    (unsigned long long)count, (unsigned long long)m, h0, (unsigned long long)nseg);
+        if (count == 0) break; // nothing is tied: the list is exact as it stands
+        if (count > ctx->t_cap) { // (contents of the tied-segment arrays are dead)
+            if ((rc = kiss_tied_reserve(ctx, count + count / 64 + 1024))) break;
+            if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, m, 0, 0, d_total))) break;
+        }
+        // ranks: never-written entries read as "no LMS position here"
+        if (hipMemsetD32Async((hipDeviceptr_t)R, (int)0xFFFFFFFFu, r_words, ctx->stream) != hipSuccess) {
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
+        if ((rc = kiss_rank_build_lms(ctx, L, ctx->lms_pos, m, n, R, pairs1, ctx->keyA, reinterpret_cast<uint32_t *>(ctx->keyB))))
+            break;
+        uint32_t *P = ctx->posA, *P2 = ctx->posB;
+        uint32_t *S = ctx->slotA, *S2 = ctx->slotB;
+        uint32_t *G = ctx->segA, *G2 = ctx->segB;
+        uint32_t *SS = ctx->segstartA, *SS2 = ctx->segstartB;
+        uint32_t *dG = ctx->bslot;
+        if ((rc = fc_compact<FC_HEADS, false>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, L, nullptr, m, 0, 0, P, S, G,
+                                              SS, nullptr, nullptr)))
+            break;
+        {
+            KTimer t(ctx, KISS_HIP_K_ISA, count);
+            hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, ctl + LX_MAXLEN);
+            hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS, count, R,
+                               ctl + LX_MAXLEN, 1);
+        }
+        uint64_t D = h0;
+        int rounds = 0;
+        while (count > 0) {
+            if (++rounds > 64 || D + 1 > n) {
+                aborted = true;
+                why = 16;
+                break;
+            }
+            const unsigned grid = (unsigned)div_up(count, T);
+            {
+                KTimer t(ctx, KISS_HIP_K_KEYGATHER, count);
+                hipLaunchKernelGGL(k_lx_ctl_init, dim3(1), dim3(64), 0, ctx->stream, ctl);
+                hipLaunchKernelGGL(k_lms_stride, dim3((unsigned)div_up(nseg, T)), dim3(T), 0, ctx->stream, ctx->pk, n, P, SS, nseg,
+                                   D, D / 2, dG, ctl);
+                hipLaunchKernelGGL(k_gather_ranks_lms, dim3(grid), dim3(T), 0, ctx->stream, R, P, G, dG, count, n, ctx->bkeyA,
+                                   ctl);
+            }
+            if ((rc = kiss_readback(ctx, ctl, 4))) break;
+            const uint32_t maxlen = ctx->h_pinned[LX_MAXLEN], min_d = ctx->h_pinned[LX_MIN_D];
+            const uint32_t nstuck = ctx->h_pinned[LX_STUCK];
+            if (ctx->h_pinned[LX_ABORT]) {
+                aborted = true;
+                why = ctx->h_pinned[LX_ABORT];
+                break;
+            }
+            uint64_t *F1 = ctx->flags, *F2 = ctx->flags + ctx->t_cap;
+            {
+                KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
+                hipLaunchKernelGGL(k_group_sort_small_lms, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, ctx->bkeyA, P, G, SS,
+                                   dG, count, D, ctx->bkeyB, ctx->bposB, maxlen > SMALL_SEG ? F1 : nullptr, ctl);
+            }
+            if (maxlen > SMALL_SEG) {
+                if ((rc = kiss_scan_u64(ctx, F1, F2, count))) break;
+                hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
+                uint64_t bt;
+                if ((rc = read_u64(ctx, d_total, &bt))) break;
+                const uint64_t nbig = bt >> 32, nbigseg = bt & 0xFFFFFFFFull;
+                if (nbig) {
+                    RadixBufs bb;
+                    bb.key[0] = ctx->keyA;
+                    bb.key[1] = ctx->keyB;
+                    bb.pos[0] = bigpos0;
+                    bb.pos[1] = bigpos1;
+                    bb.seg[0] = ctx->bsegA;
+                    bb.seg[1] = ctx->bsegB;
+                    uint32_t *bidx = ctx->bposA;
+                    {
+                        KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+                        hipLaunchKernelGGL(k_big_extract, dim3(grid), dim3(T), 0, ctx->stream, ctx->bkeyA, P, count, F1, F2, bb.key[0],
+                                           bb.pos[0], bb.seg[0], bidx);
+                    }
+                    int bres = 0;
+                    if ((rc = kiss_radix_sort(ctx, bb, nbig, 32, bits_for(nbigseg), &bres))) break;
+                    ctx->stats.big_item_rounds += nbig;
+                    KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
+                    hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)div_up(nbig, T)), dim3(T), 0, ctx->stream, bb.key[bres],
+                                       bb.pos[bres], bidx, nbig, ctx->bkeyB, ctx->bposB);
+                }
+            }
+            const uint64_t *skey = ctx->bkeyB;
+            const uint32_t *spos = ctx->bposB, *sseg = G;
+            ctx->stats.doubling_rounds++;
+            ctx->stats.sort_item_rounds += count;
+            if ((rc = fc_count<FC_KEY_SEG>(ctx, skey, sseg, count, 32, 0, d_total))) break;
+            // singletons retire into the list and the rank array; survivors are compacted (slots stay in index order)
+            if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, skey, sseg, spos, S, count, 32, 0, P2, S2, G2, SS2, L, R, nullptr, nullptr,
+                                                   nullptr, nullptr, nullptr, 1)))
+                break;
+            if ((rc = fc_read_total(ctx, d_total, &tot))) break;
+            const uint64_t ncount = tot >> 32;
+            if ((rc = kiss_readback(ctx, ctl, 4))) break; // what the sort kernel had to say
+            if (ctx->h_pinned[LX_ABORT]) {
+                aborted = true;
+                why = ctx->h_pinned[LX_ABORT];
+                break;
+            }
+            if (dbg)
+                fprintf(stderr, "[kiss_hip] lms refine D=%llu: items %llu in %llu groups (%u stuck, longest %s%u, stride >= %u) -> %llu\n",
+                        (unsigned long long)D, (unsigned long long)count, (unsigned long long)nseg, nstuck, maxlen ? "" : "<= ",
+                        maxlen ? maxlen : 64u, min_d, (unsigned long long)ncount);
+            nseg = tot & 0xFFFFFFFFull;
+            count = ncount;
+            if (min_d != 0xFFFFFFFFu) D += min_d;
+            std::swap(P, P2);
+            std::swap(S, S2);
+            std::swap(G, G2);
+            std::swap(SS, SS2);
+            if (count) {
+                KTimer t(ctx, KISS_HIP_K_ISA, count);
+                hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SS + nseg, (uint32_t)count, ctl + LX_MAXLEN);
+                hipLaunchKernelGGL(k_isa_update, dim3((unsigned)div_up(count, T)), dim3(T), 0, ctx->stream, P, S, G, SS, count, R,
+                                   ctl + LX_MAXLEN, 1);
+            }
+        }
+        if (rc || aborted) break;
+        // the suffixes that moved need the context word of their own position
+        KTimer t(ctx, KISS_HIP_K_PLACE, m);
+        hipLaunchKernelGGL(k_lms_ctx_fix, dim3((unsigned)div_up(m, T)), dim3(T), 0, ctx->stream, ctx->pk, L, C, m);
+    } while (0);
+    if (rc == KISS_HIP_OK && hipGetLastError() != hipSuccess) rc = KISS_HIP_E_HIP;
+    if (rc) return rc;
+    if (aborted) { // the list as the bounded phase left it: kiss_exact_refine takes over after the induction
+        if (dbg) fprintf(stderr, "[kiss_hip] lms refine: gave up (reason bits %u), the suffix-array form takes over\n", why);
+        ctx->stats.doubling_rounds = (uint32_t)rounds_before;
+        ctx->stats.sort_item_rounds = item_rounds_before;
+        ctx->lms_merged = false;
+        return kiss_merge_lms(ctx);
+    }
+    *resolved = true;
+    return KISS_HIP_OK;
 }
