@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KISS_HIP_VERSION 101 /* 0.1.1: kiss_hip_multi_*, stage views, ms_fm_range / ms_fm_locate in kiss_hip_stats */
+#define KISS_HIP_VERSION 102 /* 0.1.2: refine_form in kiss_hip_stats (the former reserved word) */
 
 typedef enum kiss_hip_status {
     KISS_HIP_OK = 0,
@@ -89,7 +89,9 @@ typedef struct kiss_hip_stats {
      * command/suffix_sort.hpp:57-61, is host S -> host SA) */
     float ms_h2d;             /* host S -> device */
     float ms_d2h;             /* device SA -> host */
-    uint32_t reserved_;
+    uint32_t refine_form;     /* exact order, how it was reached: 0 = doubling phase not used, 1 = rank doubling over the LMS
+                               * suffixes before the induction (KISS2's order of things, kiss2_core.hpp:835-886), 2 = rank doubling
+                               * over the whole suffix array after it (the LMS form gave up or is switched off) */
     /* kiss_hip_fmi_query_batch_dev with KISS_HIP_K_FM_QUERY timed: the two halves of ms_kernel[KISS_HIP_K_FM_QUERY] */
     float ms_fm_range;        /* backward search (get_range) */
     float ms_fm_locate;       /* get_offsets */

@@ -37,7 +37,7 @@ class Stats(ctypes.Structure):
         ("items_kernel", ctypes.c_uint64 * 16),
         ("refine_items", ctypes.c_uint64), ("refine_depth", ctypes.c_uint32), ("doubling_rounds", ctypes.c_uint32),
         ("ms_refine", ctypes.c_float), ("ms_h2d", ctypes.c_float), ("ms_d2h", ctypes.c_float),
-        ("reserved_", ctypes.c_uint32), ("ms_fm_range", ctypes.c_float), ("ms_fm_locate", ctypes.c_float),
+        ("refine_form", ctypes.c_uint32), ("ms_fm_range", ctypes.c_float), ("ms_fm_locate", ctypes.c_float),
     ]
 
     def as_dict(self):

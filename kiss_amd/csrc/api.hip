@@ -250,6 +250,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         if ((rc = kiss_induce(ctx, n, d_SA))) break;
         (void)hipEventRecord(ev[5], ctx->stream);
         if (h0 && !lms_resolved && (rc = kiss_exact_refine(ctx, n, h0, d_SA))) break;
+        if (h0 && lms_resolved) ctx->stats.refine_form = 1; // (kiss_exact_refine says 2 itself)
         (void)hipEventRecord(ev[6], ctx->stream);
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {

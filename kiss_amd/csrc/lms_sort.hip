@@ -580,7 +580,10 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           uint32_t *__restrict__ tmark, // taint marks of retiring items
                                                           const uint64_t *__restrict__ payload, // optional, with tmark: words
                                                           // whose low KISS_KEY_CTX bits are the items' context words
-                                                          int isa_shift) // isa is indexed by position >> isa_shift
+                                                          int isa_shift, // isa is indexed by position >> isa_shift
+                                                          const uint64_t *__restrict__ pk_fix, // optional, with cfix: the
+                                                          uint32_t *__restrict__ cfix) // context word of a retiring item's own
+                                                          // position is gathered from the packed text into cfix[slot]
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -632,6 +635,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                 tmark[sl] = (uint32_t)(payload[i] & KISS_KEY_CTX_MASK) | (((tl >> j) & 1u) ? KISS_CTX_TAINT : 0u);
             else if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
             if (isa) isa[p >> isa_shift] = sl;
+            if (cfix) cfix[sl] = kiss_load_ctx(pk_fix, p);
             if constexpr (SRC != FC_HEADS) {
                 if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
             }
@@ -1102,7 +1106,8 @@ template <int SRC, bool HAS_SLOT>
 int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, const uint32_t *pos, const uint32_t *slot,
                uint64_t count, int cmp_shift, int last_round, uint32_t *npos, uint32_t *nslot, uint32_t *nseg,
                uint32_t *nsegstart, uint32_t *out, uint32_t *isa, uint32_t *octx = nullptr, uint32_t *nctx = nullptr,
-               bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr, int isa_shift = 0)
+               bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr, int isa_shift = 0,
+               uint32_t *cfix = nullptr)
 {
     if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
@@ -1120,7 +1125,8 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
     else // (without slots an item's slot is its index: out == pos means the list is in place already)
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
-                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload, isa_shift);
+                           (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload, isa_shift,
+                           cfix ? ctx->pk : (const uint64_t *)nullptr, cfix);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -1583,6 +1589,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_group_heads(const uint64_t *__re
 // address take 36 ms, which is more than the kernel they were meant to speed up.  Step 2 compares the candidates' h0
 // bases with every lane busy.
 constexpr int GH_THREADS = 1024;
+constexpr int GH_ITEMS = 4;
 constexpr int GH_REGIONS = 256;
 __global__ __launch_bounds__(GH_THREADS) void k_heads_candidates(const uint32_t *__restrict__ SA, uint64_t count, uint64_t n,
                                                                 uint32_t h0, const uint32_t *__restrict__ cw,
@@ -1593,32 +1600,64 @@ __global__ __launch_bounds__(GH_THREADS) void k_heads_candidates(const uint32_t 
     __shared__ uint32_t wcount[GH_THREADS / 64];
     __shared__ uint32_t s_base;
     const uint32_t region = blockIdx.x % GH_REGIONS;
-    const uint64_t i = (uint64_t)blockIdx.x * GH_THREADS + threadIdx.x;
-    bool cand = false;
-    if (i < count) {
-        if (i > lo && (cw[i] & KISS_CTX_TAINT) && (cw[i - 1] & KISS_CTX_TAINT)) {
-            const uint64_t p = SA[i], q = SA[i - 1];
-            cand = p + h0 <= n && q + h0 <= n;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * GH_THREADS + threadIdx.x) * GH_ITEMS;
+    uint32_t cm = 0; // bit e: entry i0 + e is a candidate
+    if (i0 + GH_ITEMS <= count) { // four context words per load, four flag bytes per store
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(cw + i0);
+        const uint32_t prev = i0 > 0 ? cw[i0 - 1] : 0u;
+        const uint32_t t = (c4.x >> 31) | ((c4.y >> 31) << 1) | ((c4.z >> 31) << 2) | ((c4.w >> 31) << 3);
+        cm = t & ((t << 1) | (prev >> 31)) & 0xFu;
+#pragma unroll
+        for (int e = 0; e < GH_ITEMS; e++)
+            if (i0 + (uint64_t)e <= lo) cm &= ~(1u << e);
+        if (cm) {
+#pragma unroll
+            for (int e = 0; e < GH_ITEMS; e++)
+                if ((cm >> e) & 1u) {
+                    const uint64_t p = SA[i0 + e], q = SA[i0 + e - 1];
+                    if (!(p + h0 <= n && q + h0 <= n)) cm &= ~(1u << e);
+                }
         }
-        heads[i] = 1; // candidates that turn out tied are reset by k_heads_compare
+        *reinterpret_cast<uint32_t *>(heads + i0) = 0x01010101u; // candidates that turn out tied are reset by k_heads_compare
+    } else {
+        for (int e = 0; e < GH_ITEMS; e++) {
+            const uint64_t i = i0 + (uint64_t)e;
+            if (i >= count) break;
+            if (i > lo && (cw[i] & KISS_CTX_TAINT) && (cw[i - 1] & KISS_CTX_TAINT)) {
+                const uint64_t p = SA[i], q = SA[i - 1];
+                if (p + h0 <= n && q + h0 <= n) cm |= 1u << e;
+            }
+            heads[i] = 1;
+        }
     }
-    const uint64_t m = __ballot(cand);
+    const uint32_t c = (uint32_t)__popc(cm);
+    uint32_t inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((int)lane_id() >= d) inc += o;
+    }
     const int wave = threadIdx.x >> 6;
-    if (lane_id() == 0) wcount[wave] = (uint32_t)__popcll(m);
+    if (lane_id() == 63) wcount[wave] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int w = 0; w < GH_THREADS / 64; w++) {
-            const uint32_t c = wcount[w];
+            const uint32_t cc = wcount[w];
             wcount[w] = t;
-            t += c;
+            t += cc;
         }
         s_base = t ? atomicAdd(&ncand[region], t) : 0u;
     }
     __syncthreads();
-    if (cand) {
-        const uint64_t at = (uint64_t)s_base + wcount[wave] + (uint64_t)__popcll(m & lanemask_lt());
-        if (at < region_cap) list[(uint64_t)region * region_cap + at] = (uint32_t)i; // (an overflow shows in the counter)
+    if (cm) {
+        uint64_t at = (uint64_t)s_base + wcount[wave] + (inc - c);
+#pragma unroll
+        for (int e = 0; e < GH_ITEMS; e++)
+            if ((cm >> e) & 1u) {
+                if (at < region_cap) list[(uint64_t)region * region_cap + at] = (uint32_t)(i0 + e); // (an overflow shows in the counter)
+                at++;
+            }
     }
 }
 
@@ -1738,6 +1777,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     // heads_in == nullptr: DNA, SA ordered by h0 >= 32 bases, ties found by comparing the packed text;
     // heads_in != nullptr: the caller knows the groups already (general alphabet: equal 7-character keys)
     if ((!heads_in && h0 < 32) || h0 == 0 || n < h0) return KINTERNAL();
+    ctx->stats.refine_form = 2;
     const uint64_t total = n + 1;
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
@@ -1780,7 +1820,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 uint32_t *d_nc = ctx->rx_ghist; // GH_REGIONS counters (digit-histogram scratch of the radix sort, 3072 words, dead here)
                 const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
                 KTRY(kiss_zero_u32(ctx, d_nc, GH_REGIONS));
-                hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(total, GH_THREADS)), dim3(GH_THREADS), 0,
+                hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(total, GH_THREADS * GH_ITEMS)), dim3(GH_THREADS), 0,
                                    ctx->stream, d_SA, total, n, h0, ctx->CTX, heads, ctx->posA, region_cap, d_nc, 1u);
                 uint32_t h_nc[GH_REGIONS];
                 KCHECK(hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream));
@@ -2125,15 +2165,6 @@ __global__ __launch_bounds__(LS_THREADS) void k_group_sort_small_lms(const uint6
     opos[a + r] = pos[i];
 }
 
-// the context words of the suffixes that may have moved (the tainted ones): gathered again, taint cleared
-__global__ __launch_bounds__(LS_THREADS) void k_lms_ctx_fix(const uint64_t *__restrict__ pk, const uint32_t *__restrict__ L,
-                                                           uint32_t *__restrict__ C, uint64_t m)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= m) return;
-    if (C[i] & KISS_CTX_TAINT) C[i] = kiss_load_ctx(pk, L[i]);
-}
-
 } // namespace
 
 int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *scratch, bool *resolved)
@@ -2171,7 +2202,7 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             uint32_t *d_nc = ctx->rx_ghist;
             const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
             if ((rc = kiss_zero_u32(ctx, d_nc, GH_REGIONS))) break;
-            hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(m, GH_THREADS)), dim3(GH_THREADS), 0, ctx->stream, L, m, n,
+            hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(m, GH_THREADS * GH_ITEMS)), dim3(GH_THREADS), 0, ctx->stream, L, m, n,
                                h0, C, heads, ctx->posA, region_cap, d_nc, 0u);
             uint32_t h_nc[GH_REGIONS];
             if (hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -2203,11 +2234,7 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             if ((rc = kiss_tied_reserve(ctx, count + count / 64 + 1024))) break;
             if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, m, 0, 0, d_total))) break;
         }
-        // ranks: never-written entries read as "no LMS position here"
-        if (hipMemsetD32Async((hipDeviceptr_t)R, (int)0xFFFFFFFFu, r_words, ctx->stream) != hipSuccess) {
-            rc = KISS_HIP_E_HIP;
-            break;
-        }
+        // ranks (entries without an LMS position read as 0xFFFFFFFF)
         if ((rc = kiss_rank_build_lms(ctx, L, ctx->lms_pos, m, n, R, pairs1, ctx->keyA, reinterpret_cast<uint32_t *>(ctx->keyB))))
             break;
         uint32_t *P = ctx->posA, *P2 = ctx->posB;
@@ -2289,8 +2316,9 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             ctx->stats.sort_item_rounds += count;
             if ((rc = fc_count<FC_KEY_SEG>(ctx, skey, sseg, count, 32, 0, d_total))) break;
             // singletons retire into the list and the rank array; survivors are compacted (slots stay in index order)
+            // (and take the context word of their own position along: the list entry they replace was another suffix's)
             if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, skey, sseg, spos, S, count, 32, 0, P2, S2, G2, SS2, L, R, nullptr, nullptr,
-                                                   nullptr, nullptr, nullptr, 1)))
+                                                   nullptr, nullptr, nullptr, 1, C)))
                 break;
             if ((rc = fc_read_total(ctx, d_total, &tot))) break;
             const uint64_t ncount = tot >> 32;
@@ -2318,10 +2346,6 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
                                    ctl + LX_MAXLEN, 1);
             }
         }
-        if (rc || aborted) break;
-        // the suffixes that moved need the context word of their own position
-        KTimer t(ctx, KISS_HIP_K_PLACE, m);
-        hipLaunchKernelGGL(k_lms_ctx_fix, dim3((unsigned)div_up(m, T)), dim3(T), 0, ctx->stream, ctx->pk, L, C, m);
     } while (0);
     if (rc == KISS_HIP_OK && hipGetLastError() != hipSuccess) rc = KISS_HIP_E_HIP;
     if (rc) return rc;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = kiss_amd.load()
-    assert lib.kiss_hip_version() == 101
+    assert lib.kiss_hip_version() == 102
     assert _lib.strerror(0) == "ok"
     assert "invalid" in _lib.strerror(-1)
 

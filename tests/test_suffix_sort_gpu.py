@@ -253,6 +253,10 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
         want_dna = oracle.suffix_sort(dna, 256)
         assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
         for k in (256, 0xFFFFFFFF):
+            if k != 256:
+                # exact order through the LMS-level doubling needs no array beyond what the k = 256 sort of this text has
+                # grown already; the suffix-array form (all n suffixes tied) does: that is the growth that fails here
+                monkeypatch.setenv("KISS_HIP_NO_LMS_EXACT", "1")
             assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 700000) == 0
             with pytest.raises(kiss_amd.KissHipError) as e:
                 c.suffix_sort(acac, k)
@@ -262,6 +266,8 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
             assert e.value.status == _lib.KISS_HIP_E_NOMEM
             assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 0) == 0
             assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
+            assert np.array_equal(c.suffix_sort(acac, k), oracle.suffix_sort(acac, k))
+            monkeypatch.delenv("KISS_HIP_NO_LMS_EXACT", raising=False)
             assert np.array_equal(c.suffix_sort(acac, k), oracle.suffix_sort(acac, k))
     finally:
         c.close()
@@ -554,6 +560,72 @@ def test_more_than_a_million_near_end_suffixes(oracle):
         sa = c.suffix_sort(S, k)
         assert c.stats()["near_end"] > (1 << 20)
         assert np.array_equal(sa, want)
+
+
+def _lms_exact_shapes(shape):
+    n = 400_000
+    rng = np.random.default_rng(5)
+    if shape == "genome":
+        return gen.genome_like(1_200_000, 9)
+    if shape == "tandem":
+        return gen.periodic(600_000, 171, 5, mutations=300)
+    if shape == "run_copies":
+        # copies of stretches that hold long runs of one base: groups whose common window ends without an LMS position
+        S = gen.iid(n, 6)
+        S[1000:1700] = 0
+        S[1700] = 1
+        S[5000:5900] = 3
+        S[20_000:20_600] = 2
+        for dst in (100_000, 200_000, 300_000):
+            S[dst:dst + 30_000] = S[0:30_000]
+        return S
+    if shape == "homopolymer_arrays":
+        # arrays of one base with a few other bases sprinkled in: many LMS suffixes that start with the same long run,
+        # one "stuck" group of far more than 64 members
+        S = gen.iid(n, 7)
+        for a, base in ((10_000, 0), (150_000, 2), (280_000, 0)):
+            S[a:a + 100_000] = base
+            S[a + rng.integers(0, 100_000, 120)] = (base + 1 + rng.integers(0, 3, 120)) % 4
+        return S
+    if shape == "a1000c":  # LMS suffixes further apart than any window: the LMS form gives up, the suffix-array form takes over
+        return np.tile(np.concatenate([np.zeros(1000, np.uint8), np.ones(1, np.uint8)]), n // 1001 + 1)[:n]
+    if shape == "tail_repeat":  # the text ends inside a long copy of its own beginning: near-end suffixes in tie groups
+        base = gen.iid(n // 2, 8)
+        return np.concatenate([base, gen.iid(100, 9), base[:n // 2 - 100 - 37]])
+    if shape == "telomere_end":  # ... and inside a tandem array
+        return np.concatenate([gen.iid(n, 10), np.tile(np.array([3, 3, 0, 2, 2, 2], np.uint8), 700)])
+    raise ValueError(shape)
+
+
+@pytest.mark.parametrize("shape", ["genome", "tandem", "run_copies", "homopolymer_arrays", "a1000c", "tail_repeat",
+                                   "telomere_end"])
+def test_exact_order_lms_level_doubling(oracle, monkeypatch, shape):
+    # exact order is reached by rank doubling over the LMS suffixes BEFORE the induction (kiss_lms_exact_refine; the
+    # reference's KISS2 order of things, kiss2_core.hpp:835-886); KISS_HIP_NO_LMS_EXACT=1 is the older form (bounded phase,
+    # induction, rank doubling over the whole suffix array).  Both give THE suffix array; stats say which one ran.
+    import kiss_amd
+    S = _lms_exact_shapes(shape)
+    want = oracle.suffix_sort(S, 0xFFFFFFFF)
+    with kiss_amd.Context(max_n=S.size, device=0) as c:
+        for direct_max in (None, "1000"):   # rank array by plain scatter / by the two-level partition (isa.hip)
+            if direct_max:
+                monkeypatch.setenv("KISS_HIP_ISA_DIRECT_MAX", direct_max)
+            sa = c.suffix_sort(S, 0xFFFFFFFF, algo=1)
+            st = c.stats()
+            assert np.array_equal(sa, want), (shape, direct_max, {k: v for k, v in st.items() if k != "kernels"})
+            assert st["refine_form"] == (2 if shape == "a1000c" else 1)
+            assert st["refine_depth"] == EXACT_H0
+            if shape != "a1000c":
+                assert 0 < st["refine_items"] <= st["m"]      # tied LMS suffixes, not tied suffixes
+                assert 1 <= st["doubling_rounds"] <= 14
+        monkeypatch.delenv("KISS_HIP_ISA_DIRECT_MAX", raising=False)
+        monkeypatch.setenv("KISS_HIP_NO_LMS_EXACT", "1")
+        assert np.array_equal(c.suffix_sort(S, 0xFFFFFFFF, algo=1), want)
+        assert c.stats()["refine_form"] == 2
+        monkeypatch.delenv("KISS_HIP_NO_LMS_EXACT")
+        # k-ordered calls are untouched by any of this
+        assert np.array_equal(c.suffix_sort(S, 256), oracle.suffix_sort(S, 256))
+        assert c.stats()["refine_form"] == 0
 
 
 @pytest.mark.parametrize("shape", ["tandem", "near_end_ties", "all_tied", "genome"])
