@@ -531,6 +531,9 @@ def exact_order_leg(ctx, S, SA, n, stream, steps=3):
             "ms_per_step": 1e3 * el, "value": n / el, "unit": "bases/s", "steps": steps,
             "device_ms": st["ms_total"], "bounded_phase_order": st["refine_depth"], "doubling_ms": st["ms_refine"],
             "tied_after_bounded_phase": st["refine_items"], "doubling_rounds": st["doubling_rounds"],
+            # 1: rank doubling over the LMS suffixes before the induction (tied = tied LMS suffixes), 2: over the whole
+            # suffix array after it (the fall-back; tied = tied suffixes)
+            "doubling_over": {0: "nothing", 1: "lms_suffixes", 2: "suffix_array"}.get(st["refine_form"], "?"),
             "verified": bool(rep["ok"]), "verify": {"exact": rep["exact"], "order_violations": rep["order_violations"],
                                                     "duplicates": rep["duplicates"], "ms": rep["ms"]},
             "sa_digest": "%016x" % rep["digest"], "workspace_bytes": ctx.workspace_bytes()}

@@ -51,6 +51,7 @@ def test_bench_single_gpu_line():
     # BASELINE configs[3]: exact order through PREFIX_DOUBLING on the same text, proven on the device
     x = out["exact_order"]
     assert x["verified"] is True and x["verify"]["exact"] == 1 and x["ms_per_step"] > 0 and x["value"] > 0
+    assert x["doubling_over"] in ("lms_suffixes", "suffix_array", "nothing")
     # BASELINE configs[0]: dm-size text -- reference-code pipeline on the host cores beside the HIP path, same SA
     d = out["dm_size"]
     assert d["hip"]["ms_per_step"] > 0 and d["published"]["threads"] == 24
