@@ -27,13 +27,13 @@ constexpr int CUR_STRIDE = 64;                 // one bin cursor per 256 B: the 
 // items are pairs.  digit = (position >> shift) & 255.  Bin d of the output starts at out + ((uint64_t)d <<
 // bin_shift) and `cursor[d]` counts the pairs already placed there.
 template <bool FROM_SA>
-__global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__restrict__ SA,
-                                                             const uint64_t *__restrict__ pairs_in, uint64_t base,
-                                                             uint64_t count, int shift, int bin_shift,
-                                                             uint32_t *__restrict__ cursor, uint64_t *__restrict__ out,
-                                                             int idx_shift, // FROM_SA: the pair's index is SA[i] >> idx_shift
-                                                             const uint32_t *__restrict__ binbase, uint32_t bstride)
-// binbase (optional): bins of unequal, known size -- bin d starts at out + binbase[d * bstride] - binbase[0]
+__device__ __forceinline__ void isa_partition_tile(const uint32_t *__restrict__ SA, const uint64_t *__restrict__ pairs_in,
+                                                   uint64_t base, uint64_t count, int shift, int bin_shift,
+                                                   uint32_t *__restrict__ cursor, uint64_t *__restrict__ out, int idx_shift,
+                                                   const uint32_t *__restrict__ binbase, uint32_t bstride, uint32_t binsub,
+                                                   uint32_t tile)
+// FROM_SA: the pair's index is SA[i] >> idx_shift.
+// binbase (optional): bins of unequal, known size -- bin d starts at out + binbase[d * bstride] - binsub
 // (the sparse form, kiss_rank_build_lms: not every index has an entry) instead of at out + (d << bin_shift)
 {
     __shared__ uint64_t stage[IB_TILE];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
     __shared__ uint32_t loff[256];  // exclusive prefix of lcnt
     __shared__ uint32_t gpos[256];  // where this tile's items of bin d start inside bin d
     __shared__ uint32_t wsum[IB_THREADS / 64];
-    const uint64_t tile_base = (uint64_t)blockIdx.x * IB_TILE;
+    const uint64_t tile_base = (uint64_t)tile * IB_TILE;
     const uint32_t tile_count = (uint32_t)(count - tile_base < (uint64_t)IB_TILE ? count - tile_base : IB_TILE);
     if (threadIdx.x < 256) lcnt[threadIdx.x] = 0;
     __syncthreads();
@@ -127,10 +127,37 @@ __global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__
         if (idx < tile_count) {
             const uint64_t v = stage[idx];
             const uint32_t d = (uint32_t)(v >> (32 + shift)) & 255u;
-            const uint64_t bin0 = binbase ? (uint64_t)(binbase[d * bstride] - binbase[0]) : ((uint64_t)d << bin_shift);
+            const uint64_t bin0 = binbase ? (uint64_t)(binbase[d * bstride] - binsub) : ((uint64_t)d << bin_shift);
             out[bin0 + gpos[d] + (idx - loff[d])] = v;
         }
     }
+}
+
+template <bool FROM_SA>
+__global__ __launch_bounds__(IB_THREADS) void k_isa_partition(const uint32_t *__restrict__ SA,
+                                                             const uint64_t *__restrict__ pairs_in, uint64_t base,
+                                                             uint64_t count, int shift, int bin_shift,
+                                                             uint32_t *__restrict__ cursor, uint64_t *__restrict__ out,
+                                                             int idx_shift, const uint32_t *__restrict__ binbase,
+                                                             uint32_t bstride)
+{
+    isa_partition_tile<FROM_SA>(SA, pairs_in, base, count, shift, bin_shift, cursor, out, idx_shift, binbase, bstride,
+                                binbase ? binbase[0] : 0u, blockIdx.x);
+}
+
+// Level 2 of the sparse form for ALL level-1 bins in one launch (93 bins at chm13 size: three short launches per bin
+// left the GPU idle between them for as long as they ran).  bt: the bounds table (bin b's pairs are [bt[256 b],
+// bt[256 (b + 1)]) in pairs_in, its sub-bin s starts at bt[256 b + s] in out); tile0[b]: first workgroup of bin b.
+__global__ __launch_bounds__(IB_THREADS) void k_rank_partition_all(const uint64_t *__restrict__ pairs_in,
+                                                                  const uint32_t *__restrict__ bt,
+                                                                  const uint32_t *__restrict__ tile0, uint32_t bins,
+                                                                  uint32_t *__restrict__ cursor, uint64_t *__restrict__ out)
+{
+    uint32_t b = 0;
+    while (b + 1 < bins && tile0[b + 1] <= blockIdx.x) b++;
+    const uint32_t lo = bt[256 * b], cnt = bt[256 * (b + 1)] - lo;
+    isa_partition_tile<false>(nullptr, pairs_in + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + (uint64_t)b * 256 * CUR_STRIDE,
+                              out, 0, bt + 256 * b, 1u, 0u, blockIdx.x - tile0[b]);
 }
 
 __global__ __launch_bounds__(256) void k_isa_write(const uint64_t *__restrict__ pairs, uint64_t count,
@@ -252,18 +279,17 @@ __global__ __launch_bounds__(256) void k_lms_bounds(const uint32_t *__restrict__
 constexpr int RW_THREADS = 1024;
 constexpr int RW_SHIFT = 15;
 __global__ __launch_bounds__(RW_THREADS) void k_rank_window_write(const uint64_t *__restrict__ pairs,
-                                                                 const uint32_t *__restrict__ bt, // bounds of this bin's sub-bins
-                                                                 uint64_t idx_base, uint64_t r_words,
-                                                                 uint32_t *__restrict__ rank)
+                                                                 const uint32_t *__restrict__ bt, // bounds of all sub-bins
+                                                                 uint64_t r_words, uint32_t *__restrict__ rank)
 {
     __shared__ uint32_t win[1 << RW_SHIFT];
-    const uint32_t sub = blockIdx.x >> 1, half = blockIdx.x & 1u;
-    const uint64_t idx0 = idx_base + ((uint64_t)sub << L2_SHIFT) + ((uint64_t)half << RW_SHIFT);
+    const uint32_t sub = blockIdx.x >> 1, half = blockIdx.x & 1u; // sub-bin over all level-1 bins
+    const uint64_t idx0 = ((uint64_t)sub << L2_SHIFT) + ((uint64_t)half << RW_SHIFT);
     if (idx0 >= r_words) return;
     for (uint32_t i = threadIdx.x; i < (1u << RW_SHIFT) / 4; i += RW_THREADS)
         reinterpret_cast<uint4 *>(win)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     __syncthreads();
-    const uint32_t lo = bt[sub] - bt[0], hi = bt[sub + 1] - bt[0];
+    const uint32_t lo = bt[sub], hi = bt[sub + 1];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += RW_THREADS) {
         const uint64_t v = pairs[i];
         const uint32_t idx = (uint32_t)(v >> 32);
@@ -291,9 +317,10 @@ __global__ __launch_bounds__(256) void k_rank_direct(const uint32_t *__restrict_
 
 // L: the m LMS positions in sorted order; lms_asc: the same positions ascending.  rank: (n >> 1) + 1 words, every one of
 // them written (0xFFFFFFFF where no LMS position maps to it).
-// pairs1: m u64 of scratch; pairs2: min(m, 2^24) u64; small: 65536 + 2 u32 (bin cursors and the bounds table).
+// pairs1, pairs2: m u64 of scratch each; small: 256 KiB + 64 KiB per level-1 bin (bin cursors, bounds table, tile table:
+// <= 8.3 MiB).
 int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lms_asc, uint64_t m, uint64_t n,
-                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small)
+                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small, uint64_t small_words)
 {
     if (m == 0) return KISS_HIP_OK;
     uint64_t direct_max = 1ull << 25;
@@ -309,6 +336,7 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
     const uint64_t bins = div_up(idx_total, 1ull << L1_SHIFT);
     if (bins > 128) return KINTERNAL();
     const uint32_t sub_total = (uint32_t)(bins * 256);
+    if (512ull * CUR_STRIDE + sub_total + 1 + bins + 1 + bins * 256 * CUR_STRIDE > small_words) return KINTERNAL();
     uint32_t *cursor = small;                     // 2 x 256 strided cursors
     uint32_t *bt = small + 512 * CUR_STRIDE;      // sub_total + 1 entries
     {
@@ -328,19 +356,26 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
                            nullptr, 0ull, m, L1_SHIFT, L1_SHIFT, cursor, pairs1, 1, bt, 256u);
         KCHECK(hipGetLastError());
     }
-    KTimer t(ctx, KISS_HIP_K_ISA, m);
+    // level 2 for all bins at once, then every sub-bin as two complete windows of the rank array
+    std::vector<uint32_t> h_tile0(bins + 1);
+    uint32_t tiles = 0;
     for (uint64_t b = 0; b < bins; b++) {
-        const uint64_t lo = h_bt[256 * b], cnt = h_bt[256 * (b + 1)] - lo;
+        const uint64_t cnt = h_bt[256 * (b + 1)] - h_bt[256 * b];
         if (cnt > (1ull << L1_SHIFT)) return KINTERNAL();
-        if (cnt) {
-            KTRY(kiss_zero_u32(ctx, cursor + 256 * CUR_STRIDE, 256 * CUR_STRIDE));
-            hipLaunchKernelGGL((k_isa_partition<false>), dim3((unsigned)div_up(cnt, IB_TILE)), dim3(IB_THREADS), 0, ctx->stream,
-                               nullptr, pairs1 + lo, 0ull, cnt, L2_SHIFT, L2_SHIFT, cursor + 256 * CUR_STRIDE, pairs2, 0,
-                               bt + 256 * b, 1u);
-        }
-        hipLaunchKernelGGL(k_rank_window_write, dim3(512), dim3(RW_THREADS), 0, ctx->stream, pairs2, bt + 256 * b,
-                           b << L1_SHIFT, idx_total, rank);
-        KCHECK(hipGetLastError());
+        h_tile0[b] = tiles;
+        tiles += (uint32_t)div_up(cnt, IB_TILE);
     }
+    h_tile0[bins] = tiles;
+    uint32_t *d_tile0 = bt + sub_total + 1;
+    uint32_t *cursor2 = d_tile0 + bins + 1; // bins x 256 strided cursors
+    KCHECK(hipMemcpyAsync(d_tile0, h_tile0.data(), (bins + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    KTRY(kiss_zero_u32(ctx, cursor2, bins * 256 * CUR_STRIDE));
+    KTimer t(ctx, KISS_HIP_K_ISA, m);
+    if (tiles)
+        hipLaunchKernelGGL(k_rank_partition_all, dim3(tiles), dim3(IB_THREADS), 0, ctx->stream, pairs1, bt, d_tile0, (uint32_t)bins,
+                           cursor2, pairs2);
+    hipLaunchKernelGGL(k_rank_window_write, dim3(2 * sub_total), dim3(RW_THREADS), 0, ctx->stream, pairs2, bt, idx_total, rank);
+    KCHECK(hipGetLastError());
+    KCHECK(hipStreamSynchronize(ctx->stream)); // h_tile0 goes out of scope
     return KISS_HIP_OK;
 }

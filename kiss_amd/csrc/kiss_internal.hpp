@@ -210,7 +210,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
 int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32_t *isa);
 // rank[L[i] >> 1] = i for the m LMS positions of L (lms_asc: the same positions ascending); scratch from the caller (isa.hip)
 int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lms_asc, uint64_t m, uint64_t n,
-                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small);
+                        uint32_t *rank, uint64_t *pairs1, uint64_t *pairs2, uint32_t *small, uint64_t small_words);
 // Exact order of the LMS suffixes BEFORE the induction (lms_sort.hip): the merged h0-ordered list ctx->lmsP / ctx->lmsC is
 // refined by rank doubling over the LMS suffixes alone.  `scratch`: the (n + 1)-word suffix array buffer (not yet written).
 // *resolved = false: the list is as kiss_merge_lms left it (still h0-ordered, taint bits intact) and kiss_exact_refine has

@@ -562,6 +562,22 @@ def test_more_than_a_million_near_end_suffixes(oracle):
         assert np.array_equal(sa, want)
 
 
+def test_exact_order_lms_rank_array_two_level_one_bins(oracle, monkeypatch):
+    # the rank array of the LMS-level doubling (isa.hip: kiss_rank_build_lms) with more than one level-1 bin: indexes
+    # p >> 1 beyond 2^24 need a text of more than 2^25 bases; the second bin is short (a few sub-bins + a partial window)
+    import kiss_amd
+    monkeypatch.setenv("KISS_HIP_ISA_DIRECT_MAX", "1000")
+    n = (1 << 25) + 5 * (1 << 17) + 4321
+    S = gen.genome_like(n, 23)
+    S[3_000_000:3_400_000] = S[30_000_000:30_400_000]   # ties that reach across the two bins
+    S[n - 200_000:n - 100_000] = S[1_000_000:1_100_000]
+    with kiss_amd.Context(max_n=n, device=0) as c:
+        sa = c.suffix_sort(S, 0xFFFFFFFF, algo=1)
+        st = c.stats()
+        assert st["refine_form"] == 1 and st["refine_items"] > 100_000
+        assert np.array_equal(sa, oracle.suffix_sort(S, 0xFFFFFFFF))
+
+
 def _lms_exact_shapes(shape):
     n = 400_000
     rng = np.random.default_rng(5)
