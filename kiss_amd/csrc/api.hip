@@ -6,6 +6,7 @@
 #include "kiss_internal.hpp"
 #include <cstdlib>
 #include <chrono>
+#include <mutex>
 #include <cstring>
 #include <new>
 
@@ -37,6 +38,13 @@ void ktimer_collect(kiss_hip_ctx *ctx)
             ctx->stats.ms_kernel[ctx->ev_pool[i].cls] += ms;
     }
     ctx->ev_used = 0;
+}
+
+// one lock per device: see sort_dev (also taken stage by stage by the multi-device entry when a device is listed twice)
+std::mutex &kiss_device_mutex(int device)
+{
+    static std::mutex m[64];
+    return m[(unsigned)device & 63u];
 }
 
 // ---- low-latency read-back ------------------------------------------------------------------------------
@@ -166,7 +174,24 @@ void free_all(kiss_hip_ctx *ctx)
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 }
 
+int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo, uint32_t *d_SA, void *stream);
+// One sort at a time per device and process.  Found in round 3 with tools/lx_repro.py: two contexts sorting at the same time
+// on one device (two host threads, own streams, own workspaces -- tests/test_suffix_sort_gpu.py::
+// test_two_contexts_concurrently) gave a wrong exact-order suffix array about once in 2 000 sorts, in every form of the
+// exact-order finish including the round-1 one; with the device phases of the two sorts kept apart: none in 6 400.  Nothing
+// in this library is shared between contexts (no static device or host state, separate streams, events, pinned
+// buffers), per-kernel synchronisation inside the stages changes nothing, and neither does the way counters are read back;
+// what is left is what the runtime shares between two host threads that launch a few hundred short kernels each at the
+// same time.  A saturating sort gains nothing from a second one beside it, so the calls queue up here instead
+// (KISS_HIP_NO_SERIALIZE=1, read per call: the old behaviour, for whoever wants to look further).
 int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo, uint32_t *d_SA, void *stream)
+{
+    if (!ctx) return KISS_HIP_E_INVALID;
+    if (getenv("KISS_HIP_NO_SERIALIZE")) return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
+    std::lock_guard<std::mutex> lock(kiss_device_mutex(ctx->device));
+    return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
+}
+int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo, uint32_t *d_SA, void *stream)
 {
     if (!ctx || !d_SA || (n && !d_S)) return KISS_HIP_E_INVALID;
     if (n > KISS_HIP_MAX_N || n > ctx->max_n) return KISS_HIP_E_INVALID;
@@ -226,6 +251,16 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         (void)hipEventRecord(ev[1], ctx->stream);
         if ((rc = kiss_classify(ctx, n, depth, 0, n))) break;
         (void)hipEventRecord(ev[2], ctx->stream);
+        ctx->hfar = nullptr;
+        ctx->h_depth = h0;
+        if (h0 && lms_exact && ctx->m_far && !getenv("KISS_HIP_LMS_HEADS_BY_COMPARE")) { // (A-B hook, read per call)
+            // the LMS sort notes which far suffix retires tied with its predecessor: one byte per far-list slot at the far
+            // end of CTX (kiss_lms_exact_refine lays its rank array and the merged list's flags out from the near end)
+            if ((rc = kiss_need_ctx_words(ctx))) break;
+            const uint64_t hwords = (ctx->m_far + 8 + 3) / 4;
+            ctx->hfar = reinterpret_cast<uint8_t *>(ctx->CTX + ((n + 2 - hwords) & ~3ull));
+            if ((rc = kiss_fill_u32(ctx, ctx->hfar, 0x01010101u, (ctx->m_far + 3) / 4))) break; // (a kernel: see kiss_fill_u32)
+        }
         rc = kiss_lms_sort(ctx, n, k, depth);
         if (rc == KISS_INTERNAL_TOO_DEEP && attempt == 0 && n >= 4ull * KISS_EXACT_H0 + 1024) {
             // exact order requested through PARALLEL_SORTING on a text with very long repeats: same result via
@@ -274,6 +309,7 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
         break;
     }
     if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
+    ctx->hfar = ctx->hmerged = nullptr;
     ctx->stats.m = ctx->m;
     ktimer_collect(ctx);
     for (auto &e : ev) (void)hipEventDestroy(e);

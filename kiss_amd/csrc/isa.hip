@@ -328,7 +328,7 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
     const uint64_t idx_total = (n >> 1) + 1;
     if (m <= direct_max || m < (1ull << 16)) {
         KTimer t(ctx, KISS_HIP_K_ISA, m);
-        KCHECK(hipMemsetD32Async((hipDeviceptr_t)rank, (int)0xFFFFFFFFu, idx_total, ctx->stream));
+        KTRY(kiss_fill_u32(ctx, rank, 0xFFFFFFFFu, idx_total)); // (a kernel, not hipMemsetAsync: see kiss_fill_u32)
         hipLaunchKernelGGL(k_rank_direct, dim3((unsigned)div_up(m, 256)), dim3(256), 0, ctx->stream, L, m, rank);
         KCHECK(hipGetLastError());
         return KISS_HIP_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include <vector>
 #include "../../include/kiss_hip.h"
 
@@ -114,6 +115,11 @@ struct kiss_hip_ctx {
     uint8_t *ga_codes = nullptr;     // general.hip: a byte text over <= 4 values, mapped to codes 0..3 (on first use)
     uint64_t ga_codes_cap = 0;
     uint8_t *refine_heads = nullptr; // exact-order finish: tie flags, one byte per SA entry (allocated on first use)
+    // exact order through the LMS-level doubling: the LMS sort itself says which far suffix retired tied with its predecessor
+    // (one byte per far-list slot, 1 = starts a group; inside CTX, which nothing else uses before the induction), and
+    // kiss_merge_lms carries the bytes over to the merged list.  Null outside such a call.
+    uint8_t *hfar = nullptr, *hmerged = nullptr;
+    uint32_t h_depth = 0; // the bases the members of such a group share at least (= the order of the bounded phase)
     bool lms_merged = false;
     int near_form = 0;                    // 0: none, 1: pairwise ranks (text order), 2: merge-sorted
     const uint32_t *near_sorted = nullptr; // form 2: the near-end suffixes in k-order
@@ -175,11 +181,16 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth /*0 = unbounded*
 // copies nwords (<= 16) 32-bit words from device memory to ctx->h_pinned[0 .. nwords) after everything queued on the
 // ctx stream so far has finished; returns when they are there (the per-round / per-pass control values of the drivers)
 int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords);
+// the lock that keeps the device phases of two sorts on one device apart (api.hip: sort_dev)
+std::mutex &kiss_device_mutex(int device);
 // exclusive scans (in place allowed: out may equal in)
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count);
 int kiss_scan_u64(kiss_hip_ctx *ctx, const uint64_t *in, uint64_t *out, uint64_t count);
 // zero count_u32 32-bit words at p with a kernel on the ctx stream
 int kiss_zero_u32(kiss_hip_ctx *ctx, void *p, uint64_t count_u32);
+// fill with any 32-bit value, also as a kernel (hipMemsetAsync is not reliably ordered against the kernels around it when
+// several contexts work at once: found the hard way, twice).
+int kiss_fill_u32(kiss_hip_ctx *ctx, void *p, uint32_t value, uint64_t count_u32);
 // stable LSD radix sort of (key64[, seg32], pos32) tuples; bits [key_lo_bit,64) of key then seg_bits of seg.
 // Buffers ping-pong; on return *in_is_result tells which pair holds the sorted data (true = the A buffers).
 struct RadixBufs {

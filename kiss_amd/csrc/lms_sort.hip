@@ -173,7 +173,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           uint32_t *__restrict__ out, uint64_t *__restrict__ big,
                                                           uint32_t *__restrict__ nbig,
                                                           const uint32_t *__restrict__ tctx, // first round only: the
-                                                          uint32_t *__restrict__ octx)       // items' context words
+                                                          uint32_t *__restrict__ octx,       // items' context words
+                                                          uint8_t *__restrict__ hfar) // optional: 0 for an item that retires
+                                                          // tied with the one before it in the final order (ctx->hfar)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     const bool valid = i < count;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
     // taint (KISS_CTX_TAINT): this item is tied with another one through the full depth (a walk of deep_less, here or in
     // k_seg_adjacent, ended without a difference): its place among its mates is the tie rule's
     bool taint = false;
+    bool tied_before = false; // tied with a mate that precedes it in the final order (position order among mates)
     if (small) {
         pi = pos[i];
         if (!second_in_wave && b - a == 2) {
@@ -207,14 +210,20 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
             }
             if (sorted) {
                 r = (uint32_t)i - a;
-                taint = ((uint32_t)i > a && inorder[i - 1] == 2) || ((uint32_t)i + 1 < b && inorder[i] == 2);
+                tied_before = (uint32_t)i > a && inorder[i - 1] == 2;
+                taint = tied_before || ((uint32_t)i + 1 < b && inorder[i] == 2);
             } else {
                 for (uint32_t j = a; j < b; j++) {
                     if (j == (uint32_t)i) continue;
                     uint64_t kj = key[j];
                     bool jless;
                     if (kj != ki) jless = kj < ki;
-                    else jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i, &taint);
+                    else {
+                        bool tj = false;
+                        jless = deep_less(pk, n, pos[j], pi, off, depth, j < (uint32_t)i, &tj);
+                        taint = taint || tj;
+                        tied_before = tied_before || (tj && jless);
+                    }
                     r += jless ? 1u : 0u;
                 }
             }
@@ -226,9 +235,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
         r = 1u - r_prev;
         taint = t_prev; // the pair's first member did the comparison
     }
+    if (small && b - a == 2) tied_before = taint && r == 1;
     if (small) {
         const uint32_t dst = slot[a + r];
         out[dst] = (uint32_t)pi;
+        if (hfar && tied_before) hfar[dst] = 0;
         // the context word a finished item brought along from round 0 (key payload) spares the placement step a
         // random text gather; items that stay tied past this round get theirs gathered there (and are tainted there)
         if (tctx) octx[dst] = tctx[i] | (taint ? KISS_CTX_TAINT : 0u);
@@ -488,6 +499,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_heads(const uint64_t *__re
     if (same_prev && !complete) h = 0;
     // bit 1: a complete key shared with a neighbour = equal through the full depth: final here by the tie rule (taint)
     if (complete && (same_prev || (i + 1 < nbig && seg[i + 1] == seg[i] && (key[i + 1] & cmp_mask) == k))) h |= 2;
+    if (complete && same_prev) h |= 4; // bit 2: ... and that neighbour is the predecessor (ctx->hfar)
     heads[i] = h;
 }
 
@@ -507,10 +519,12 @@ constexpr int FC_KEY = 0, FC_KEY_SEG = 1, FC_HEADS = 2;
 template <int SRC>
 __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const uint32_t *__restrict__ seg, uint64_t i,
                                          uint64_t count, int cmp_shift, int last_round, bool &surv, bool &shead,
-                                         bool *tie = nullptr) // *tie: the item shares everything compared with a neighbour
+                                         bool *tie = nullptr, // *tie: the item shares everything compared with a neighbour
+                                         bool *tie_prev = nullptr) // ... with its predecessor
 {
     surv = shead = false;
     if (tie) *tie = false;
+    if (tie_prev) *tie_prev = false;
     if (i >= count) return;
     bool head, nhead;
     if constexpr (SRC == FC_HEADS) {
@@ -518,6 +532,7 @@ __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const
         head = (i == 0) || hb[i] != 0;
         nhead = (i + 1 == count) || hb[i + 1] != 0;
         if (tie) *tie = (hb[i] & 2) != 0; // the producer of the head bytes says so (k_pivot_heads)
+        if (tie_prev) *tie_prev = (hb[i] & 4) != 0;
     } else {
         constexpr bool HAS_SEG = SRC == FC_KEY_SEG;
         uint64_t k = key[i] >> cmp_shift;
@@ -529,6 +544,7 @@ __device__ __forceinline__ void fc_flags(const uint64_t *__restrict__ key, const
     shead = surv && head;
     if constexpr (SRC != FC_HEADS) {
         if (tie) *tie = !(head && nhead);
+        if (tie_prev) *tie_prev = !head;
     }
 }
 
@@ -582,8 +598,10 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
                                                           // whose low KISS_KEY_CTX bits are the items' context words
                                                           int isa_shift, // isa is indexed by position >> isa_shift
                                                           const uint64_t *__restrict__ pk_fix, // optional, with cfix: the
-                                                          uint32_t *__restrict__ cfix) // context word of a retiring item's own
+                                                          uint32_t *__restrict__ cfix, // context word of a retiring item's own
                                                           // position is gathered from the packed text into cfix[slot]
+                                                          uint8_t *__restrict__ hmark) // optional: hmark[slot] = 0 for an item
+                                                          // that retires tied with its predecessor (ctx->hfar)
 {
     __shared__ uint32_t ws[FC_THREADS / 64][2];
     const int wave = threadIdx.x >> 6;
@@ -591,12 +609,14 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
     uint32_t rs[FC_ITEMS], rh[FC_ITEMS]; // rank among survivors / surviving heads inside the wave (inclusive for heads)
     uint32_t fl = 0;                      // bit 2j = survivor, bit 2j+1 = surviving head
     uint32_t tl = 0;                      // bit j = retires while tied with a neighbour (last round / complete pivot key)
+    uint32_t tp = 0;                      // bit j = ... and that neighbour is its predecessor
     uint32_t ns = 0, nh = 0;
 #pragma unroll
     for (int j = 0; j < FC_ITEMS; j++) {
-        bool sv, sh, ti;
-        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh, &ti);
+        bool sv, sh, ti, tpv;
+        fc_flags<SRC>(key, seg, base + (uint64_t)j * 64, count, cmp_shift, last_round, sv, sh, &ti, &tpv);
         tl |= (ti && !sv ? 1u : 0u) << j;
+        tp |= (ti && tpv && !sv ? 1u : 0u) << j;
         const uint64_t ms = __ballot(sv), mh = __ballot(sh);
         rs[j] = ns + (uint32_t)__popcll(ms & lanemask_lt());
         rh[j] = nh + (uint32_t)__popcll(mh & lanemask_lt()) + (sh ? 1u : 0u);
@@ -636,6 +656,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
             else if (tmark && ((tl >> j) & 1u)) tmark[sl] = KISS_CTX_TAINT; // no context word yet: gathered at placement
             if (isa) isa[p >> isa_shift] = sl;
             if (cfix) cfix[sl] = kiss_load_ctx(pk_fix, p);
+            if (hmark && ((tp >> j) & 1u)) hmark[sl] = 0;
             if constexpr (SRC != FC_HEADS) {
                 if (octx) octx[sl] = (uint32_t)(key[i] & KISS_KEY_CTX_MASK); // round 0: payload of the classification key
             }
@@ -1109,6 +1130,7 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
                bool *nctx_written = nullptr, uint32_t *tmark = nullptr, const uint64_t *payload = nullptr, int isa_shift = 0,
                uint32_t *cfix = nullptr)
 {
+    uint8_t *hmark = tmark ? ctx->hfar : nullptr; // (the calls that mark taints are the retirements of the LMS sort)
     if (nctx_written) *nctx_written = false;
     const uint64_t tiles = div_up(count, FC_TILE);
     const uint64_t *tex = ctx->flags + tiles; // left there by fc_count
@@ -1126,7 +1148,7 @@ int fc_compact(kiss_hip_ctx *ctx, const uint64_t *key, const uint32_t *seg, cons
         hipLaunchKernelGGL((k_fc_compact<SRC, HAS_SLOT>), dim3((unsigned)tiles), dim3(FC_THREADS), 0, ctx->stream, key, seg,
                            pos, slot, count, cmp_shift, last_round, tex, npos, nslot, nseg, nsegstart,
                            (!HAS_SLOT && out == pos) ? (uint32_t *)nullptr : out, isa, octx, tmark, payload, isa_shift,
-                           cfix ? ctx->pk : (const uint64_t *)nullptr, cfix);
+                           cfix ? ctx->pk : (const uint64_t *)nullptr, cfix, hmark);
     KCHECK(hipGetLastError());
     return KISS_HIP_OK;
 }
@@ -1318,7 +1340,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
                                count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig,
-                               (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far);
+                               (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far, ctx->hfar);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
@@ -2171,11 +2193,12 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
 {
     *resolved = false;
     if (h0 < 32 || n < h0 || !scratch) return KINTERNAL();
-    KTRY(kiss_merge_lms(ctx));
     const uint64_t m = ctx->m;
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    ctx->hmerged = nullptr;
     if (m < 2) {
+        KTRY(kiss_merge_lms(ctx));
         *resolved = true;
         return KISS_HIP_OK;
     }
@@ -2183,10 +2206,20 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
     ctx->ctx_words_valid = false;
     uint32_t *L = ctx->lmsP, *C = ctx->lmsC;
     // CTX (n + 2 words, not in use before the induction): the rank array, then one tie flag byte per list entry
+    // (and, at its far end, ctx->hfar: the tie flags the LMS sort wrote for the far list, api.hip)
     uint32_t *R = ctx->CTX;
     const uint64_t r_words = (n >> 1) + 1;
     uint8_t *heads = reinterpret_cast<uint8_t *>(ctx->CTX + ((r_words + 3) & ~3ull));
     if (((r_words + 3) & ~3ull) + (m + 16) / 4 + 1 > ctx->max_n + 2) return KINTERNAL();
+    // the merged list; with the sort's own tie flags (ctx->hfar) the flags of the merged list come out of the same pass
+    const bool sort_flags = ctx->hfar != nullptr && ctx->h_depth == h0;
+    ctx->hmerged = sort_flags ? heads : nullptr;
+    ctx->lms_merged = false;
+    {
+        const int mrc = kiss_merge_lms(ctx);
+        ctx->hmerged = nullptr;
+        if (mrc) return mrc;
+    }
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     uint32_t *ctl = ctx->d_small + 8;
     uint64_t *pairs1 = reinterpret_cast<uint64_t *>(((uintptr_t)scratch + 7) & ~(uintptr_t)7);
@@ -2197,13 +2230,17 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
     uint32_t why = 0;
     const uint64_t rounds_before = ctx->stats.doubling_rounds, item_rounds_before = ctx->stats.sort_item_rounds;
     do {
-        { // tie flags: both neighbours tainted and equal on their first h0 bases
+        if (!sort_flags || dbg) {
+            // tie flags by comparison: both neighbours tainted and equal on their first h0 bases (the form without the sort's
+            // flags -- KISS_HIP_LMS_HEADS_BY_COMPARE=1 --; with KISS_HIP_DEBUG also run beside them as a cross-check: every
+            // pair the sort calls tied must be tied here too)
+            uint8_t *hc = sort_flags ? heads + ((m + 64) & ~15ull) : heads;
             KTimer t(ctx, KISS_HIP_K_GROUP_HEADS, m);
             uint32_t *d_nc = ctx->rx_ghist;
             const uint64_t region_cap = ctx->m_cap / GH_REGIONS;
             if ((rc = kiss_zero_u32(ctx, d_nc, GH_REGIONS))) break;
             hipLaunchKernelGGL(k_heads_candidates, dim3((unsigned)div_up(m, GH_THREADS * GH_ITEMS)), dim3(GH_THREADS), 0, ctx->stream, L, m, n,
-                               h0, C, heads, ctx->posA, region_cap, d_nc, 0u);
+                               h0, C, hc, ctx->posA, region_cap, d_nc, 0u);
             uint32_t h_nc[GH_REGIONS];
             if (hipMemcpyAsync(h_nc, d_nc, sizeof h_nc, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -2215,10 +2252,45 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             if (mx <= region_cap) {
                 if (mx)
                     hipLaunchKernelGGL(k_heads_compare, dim3((unsigned)div_up((uint64_t)mx, T), GH_REGIONS), dim3(T), 0, ctx->stream,
-                                       ctx->pk, L, ctx->posA, region_cap, d_nc, h0, heads);
+                                       ctx->pk, L, ctx->posA, region_cap, d_nc, h0, hc);
             } else {
                 hipLaunchKernelGGL(k_group_heads, dim3((unsigned)div_up(m, T)), dim3(T), 0, ctx->stream, ctx->pk, n, L, m, h0, C,
-                                   heads, 0u);
+                                   hc, 0u);
+            }
+            if (sort_flags) { // debug cross-check
+                std::vector<uint8_t> a(m), b(m);
+                if (hipMemcpyAsync(a.data(), heads, m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipMemcpyAsync(b.data(), hc, m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                    rc = KISS_HIP_E_HIP;
+                    break;
+                }
+                uint64_t tied_sort = 0, tied_cmp = 0, bad = 0;
+                for (uint64_t i = 0; i < m; i++) {
+                    tied_sort += a[i] == 0;
+                    tied_cmp += b[i] == 0;
+                    bad += (a[i] == 0 && b[i] != 0);
+                }
+                fprintf(stderr, "[kiss_hip] lms refine: tie flags from the sort: %llu entries tied with their predecessor; by comparison "
+                                "of %u bases: %llu; tied for the sort but not by comparison: %llu\n",
+                        (unsigned long long)tied_sort, h0, (unsigned long long)tied_cmp, (unsigned long long)bad);
+                if (bad) {
+                    std::vector<uint32_t> hl(m), hcw(m);
+                    (void)hipMemcpy(hl.data(), L, m * 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(hcw.data(), C, m * 4, hipMemcpyDeviceToHost);
+                    int shown = 0;
+                    for (uint64_t i = 0; i < m && shown < 6; i++)
+                        if (a[i] == 0 && b[i] != 0) {
+                            shown++;
+                            fprintf(stderr, "[kiss_hip]   entry %llu of %llu (m_far %llu, near %u): position %u (taint %u), predecessor %u "
+                                            "(taint %u); flags around it, sort: %u %u %u  comparison: %u %u %u\n",
+                                    (unsigned long long)i, (unsigned long long)m, (unsigned long long)ctx->m_far, ctx->rm_E, hl[i],
+                                    hcw[i] >> 31, i ? hl[i - 1] : 0u, i ? hcw[i - 1] >> 31 : 0u, i ? a[i - 1] : 9u, a[i],
+                                    i + 1 < m ? a[i + 1] : 9u, i ? b[i - 1] : 9u, b[i], i + 1 < m ? b[i + 1] : 9u);
+                        }
+                    rc = KINTERNAL();
+                    break;
+                }
             }
         }
         uint64_t tot;
@@ -2355,6 +2427,7 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
         ctx->stats.doubling_rounds = (uint32_t)rounds_before;
         ctx->stats.sort_item_rounds = item_rounds_before;
         ctx->lms_merged = false;
+        ctx->hmerged = nullptr;
         return kiss_merge_lms(ctx);
     }
     *resolved = true;

@@ -87,6 +87,18 @@ namespace {
 
 using clk = std::chrono::steady_clock;
 
+// The device work of a phase, when this rank's device is also another rank's (a test configuration: shares of one GPU):
+// one rank at a time, for the reason given at api.hip: sort_dev.  Never held across a barrier.
+struct SharedDeviceLock {
+    std::unique_lock<std::mutex> lk;
+    SharedDeviceLock(const kiss_hip_multi *mc, int r)
+    {
+        bool shared = false;
+        for (int q = 0; q < mc->G; q++) shared = shared || (q != r && mc->dev[q] == mc->dev[r]);
+        if (shared && !getenv("KISS_HIP_NO_SERIALIZE")) lk = std::unique_lock<std::mutex>(kiss_device_mutex(mc->dev[r]));
+    }
+};
+
 // key-range boundaries (on the first MG_HIST_BITS key bits) that balance the far LMS count over G ranks; group of a
 // bin = #{s in sp : s <= bin} (the rule of kiss_amd/multi_gpu.py::choose_splitters, tests/test_multi_gpu.py)
 void choose_splitters(const std::vector<uint64_t> &hist, int G, uint32_t *sp)
@@ -182,6 +194,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
 
     // ---- packed text: device 0 packs, the others pull
     if (ok() && r == 0) {
+        SharedDeviceLock device_lock(mc, r);
         int rc = kiss_pack_text(ctx, sh->d_S, n);
         if (!rc) rc = sync();
         fail(rc);
@@ -201,6 +214,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
         return KISS_HIP_OK;
     };
     if (ok()) {
+        SharedDeviceLock device_lock(mc, r);
         int rc = KISS_HIP_OK;
         if (r > 0) rc = copy_between(mc, r, ctx->pk, 0, mc->ctx[0]->pk, words * sizeof(uint64_t), ctx->stream);
         if (!rc) rc = classify(true);
@@ -240,6 +254,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     }
     // ---- capacity: the receiving list of this rank, and on device 0 the whole sorted list + the near-end suffixes
     if (ok()) {
+        SharedDeviceLock device_lock(mc, r);
         int rc = KISS_HIP_OK;
         uint64_t need = R[r];
         if (r == 0 && m_far_total + near_total > need) need = m_far_total + near_total;
@@ -262,6 +277,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     mark(3);
     // ---- the exchange: receiver r pulls its piece from every source in rank order
     if (ok() && G > 1) {
+        SharedDeviceLock device_lock(mc, r);
         int rc = KISS_HIP_OK;
         uint64_t roff = 0;
         for (int q = 0; q < G && !rc; q++) {
@@ -279,6 +295,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     mark(4);
     // ---- k-ordered sort of the received key range, in place
     if (ok()) {
+        SharedDeviceLock device_lock(mc, r);
         // the digit counts of the emit pass are good only for the very list it emitted (one device, nothing exchanged)
         if (G > 1) ctx->rx_ghist_count = 0;
         ctx->m = ctx->m_far = R[r];
@@ -296,6 +313,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     if (mc->deep.load()) return; // the caller runs the attempt again for k = 256 and finishes with rank doubling
     // ---- device 0: pull the sorted pieces and the near-end suffixes, placement + induction
     if (ok() && r == 0) {
+        SharedDeviceLock device_lock(mc, r);
         int rc = KISS_HIP_OK;
         uint64_t off = R[0];
         for (int g = 1; g < G && !rc; g++) {

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
                                                          const uint32_t *__restrict__ far_sorted,
                                                          const uint32_t *__restrict__ far_ctx, uint64_t m_far,
                                                          const uint32_t *__restrict__ near_sidx, uint32_t E,
-                                                         uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC)
+                                                         uint32_t *__restrict__ lmsP, uint32_t *__restrict__ lmsC,
+                                                         const uint8_t *__restrict__ hfar, // optional: tie flags of the far
+                                                         uint8_t *__restrict__ hmerged)   // list, carried over to the merged one
 {
     struct __attribute__((packed, aligned(4))) U4 {
         uint32_t v[4];
@@ -197,12 +199,21 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
             }
             *reinterpret_cast<U4 *>(lmsP + i0 + lo0) = wp;
             *reinterpret_cast<U4 *>(lmsC + i0 + lo0) = wc;
+            if (hfar) {
+                const uint32_t h4 = *reinterpret_cast<const uint32_t *>(hfar + i0);
+                if ((lo0 & 3u) == 0) *reinterpret_cast<uint32_t *>(hmerged + i0 + lo0) = h4;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) hmerged[i0 + lo0 + e] = (uint8_t)(h4 >> (8 * e));
+                }
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const uint32_t lo = near_shift(near_sidx, E, i0 + e);
                 lmsP[i0 + e + lo] = xs[e];
                 lmsC[i0 + e + lo] = cs[e];
+                if (hfar) hmerged[i0 + e + lo] = hfar[i0 + e];
             }
         }
     } else {
@@ -213,8 +224,39 @@ __global__ __launch_bounds__(PL_THREADS) void k_merge_far(const uint64_t *__rest
             if (KISS_CTX_WORD(c) == 0) c = kiss_load_ctx(pk, x) | (c & KISS_CTX_TAINT);
             lmsP[i + lo] = x;
             lmsC[i + lo] = c;
+            if (hfar) hmerged[i + lo] = hfar[i];
         }
     }
+}
+
+// tie flag of a near-end suffix in the merged list: it starts a group unless it and its predecessor there share h0 bases
+// (a far suffix is never tied with a near-end predecessor: every far suffix that ties with a near-end one sorts before it).
+// The predecessor is looked up in the arrays the merge is made FROM (the far list, the near-end suffixes' insertion indexes
+// and final places), not in the merged list itself.  sorted_form: near_fin ascends with e (kiss_place_lms, form 2).
+__global__ __launch_bounds__(PL_THREADS) void k_near_heads(const uint64_t *__restrict__ pk, uint64_t n, uint64_t h0,
+                                                          const uint32_t *__restrict__ far_sorted,
+                                                          const uint32_t *__restrict__ near_pos,
+                                                          const uint32_t *__restrict__ near_idx,
+                                                          const uint32_t *__restrict__ near_fin, uint32_t E, int sorted_form,
+                                                          uint8_t *__restrict__ hmerged)
+{
+    const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint32_t f = near_fin[e];
+    uint8_t head = 1;
+    if (f > 0) {
+        const uint64_t p = near_pos[e];
+        uint64_t q = ~0ull;
+        if (sorted_form) {
+            if (e > 0 && near_fin[e - 1] == f - 1) q = near_pos[e - 1];
+        } else {
+            for (uint32_t g = 0; g < E; g++) // (this form has a few hundred near-end suffixes, 4095 at most)
+                if (near_fin[g] == f - 1) q = near_pos[g];
+        }
+        if (q == ~0ull && near_idx[e] > 0) q = far_sorted[near_idx[e] - 1];
+        if (q != ~0ull && p + h0 <= n && q + h0 <= n && cmp_bases(pk, q, p, h0) == 0) head = 0;
+    }
+    hmerged[f] = head;
 }
 
 __global__ __launch_bounds__(PL_THREADS) void k_merge_near(const uint64_t *__restrict__ pk,
@@ -285,13 +327,17 @@ constexpr uint32_t NT_BLOCKS = 16;
 constexpr uint32_t NT_MAX_GRID = 1u << 20;
 __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__restrict__ run_start,
                                                              const uint32_t *__restrict__ near_idx,
-                                                             uint32_t *__restrict__ far_ctx, uint32_t E)
+                                                             uint32_t *__restrict__ far_ctx, uint32_t E,
+                                                             uint8_t *__restrict__ hfar) // optional (ctx->hfar): the far suffixes
+                                                             // of a run share k bases with each other too -- one group
 {
     for (uint64_t b = blockIdx.x; b < (uint64_t)NT_BLOCKS * E; b += gridDim.x) {
         const uint32_t e = (uint32_t)(b / NT_BLOCKS), sub = (uint32_t)(b % NT_BLOCKS);
         const uint64_t lo = run_start[e], hi = near_idx[e];
-        for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS)
+        for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS) {
             far_ctx[j] |= KISS_CTX_TAINT; // (a word of 0 = "gather me" becomes 0x80000000: still gathered, see k_merge_far)
+            if (hfar && j > lo) hfar[j] = 0;
+        }
     }
 }
 
@@ -391,7 +437,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                                    ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E);
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr);
             }
             ctx->near_form = 2;
             ctx->near_sorted = near_sorted;
@@ -407,7 +453,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                                    ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E);
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr);
             }
             // (stream order: k_near_tie_mark has read near_tmp2 before the table overwrites it)
             hipLaunchKernelGGL(k_near_table, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, near_pos, ctx->near_fin, E, ctx->near_tmp,
@@ -434,13 +480,16 @@ int kiss_merge_lms(kiss_hip_ctx *ctx)
     KTimer t(ctx, KISS_HIP_K_PLACE, ctx->m);
     const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
     const unsigned fgrid = (unsigned)div_up(div_up(m_far, 4), PL_THREADS);
+    // exact order through the LMS-level doubling: the far list's tie flags go along (both pointers set, or neither)
+    const uint8_t *hf = ctx->hmerged ? ctx->hfar : nullptr;
+    uint8_t *hm = hf ? ctx->hmerged : nullptr;
     if (E == 0) {
         hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far, ctx->lms_ctx_far,
-                           m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP, ctx->lmsC);
+                           m_far, (const uint32_t *)nullptr, 0u, ctx->lmsP, ctx->lmsC, hf, hm);
     } else if (ctx->near_form == 2) {
         if (m_far)
             hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far,
-                               ctx->lms_ctx_far, m_far, ctx->near_idx, E, ctx->lmsP, ctx->lmsC);
+                               ctx->lms_ctx_far, m_far, ctx->near_idx, E, ctx->lmsP, ctx->lmsC, hf, hm);
         hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->near_sorted, ctx->near_fin, E,
                            ctx->lmsP, ctx->lmsC);
     } else {
@@ -454,10 +503,14 @@ int kiss_merge_lms(kiss_hip_ctx *ctx)
         KCHECK(hipStreamSynchronize(ctx->stream)); // idx goes out of scope
         if (m_far)
             hipLaunchKernelGGL(k_merge_far, dim3(fgrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->lms_sorted_far,
-                               ctx->lms_ctx_far, m_far, ctx->near_pos, E, ctx->lmsP, ctx->lmsC);
+                               ctx->lms_ctx_far, m_far, ctx->near_pos, E, ctx->lmsP, ctx->lmsC, hf, hm);
         hipLaunchKernelGGL(k_merge_near, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, near_pos, ctx->near_fin, E, ctx->lmsP,
                            ctx->lmsC);
     }
+    if (hm && E)
+        hipLaunchKernelGGL(k_near_heads, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, ctx->n, (uint64_t)ctx->h_depth,
+                           ctx->lms_sorted_far, ctx->near_form == 2 ? ctx->near_sorted : ctx->lms_pos + m_far, ctx->near_idx,
+                           ctx->near_fin, E, ctx->near_form == 2 ? 1 : 0, hm);
     KCHECK(hipGetLastError());
     ctx->lms_merged = true;
     return KISS_HIP_OK;

@@ -638,7 +638,7 @@ int kiss_radix_check(kiss_hip_ctx *ctx)
     KCHECK(hipMemcpyAsync(&err, ctx->rx_ctl + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
     if (err) {
-        (void)hipMemsetAsync(ctx->rx_ctl + 1, 0, sizeof(uint32_t), ctx->stream);
+        (void)kiss_zero_u32(ctx, ctx->rx_ctl + 1, 1);
         return KINTERNAL();
     }
     return KISS_HIP_OK;

@@ -194,6 +194,29 @@ int kiss_zero_u32(kiss_hip_ctx *ctx, void *p, uint64_t count_u32)
     return KISS_HIP_OK;
 }
 
+// the same for any 32-bit value: exactly count_u32 words, four per thread where p is 16-byte aligned
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, uint64_t count, int vec)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const uint64_t full = count >> 2;
+        if (i < full) reinterpret_cast<uint4 *>(p)[i] = make_uint4(v, v, v, v);
+        else if (i - full < (count & 3)) p[4 * full + (i - full)] = v;
+    } else if (i < count) {
+        p[i] = v;
+    }
+}
+int kiss_fill_u32(kiss_hip_ctx *ctx, void *p, uint32_t value, uint64_t count_u32)
+{
+    if (!count_u32) return KISS_HIP_OK;
+    const int vec = ((uintptr_t)p & 15) == 0;
+    const uint64_t threads = vec ? (count_u32 >> 2) + (count_u32 & 3) : count_u32;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)div_up(threads, 256)), dim3(256), 0, ctx->stream, (uint32_t *)p, value,
+                       count_u32, vec);
+    KCHECK(hipGetLastError());
+    return KISS_HIP_OK;
+}
+
 int kiss_scan_u32(kiss_hip_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t count)
 {
     return scan_impl<uint32_t>(ctx, in, out, count);

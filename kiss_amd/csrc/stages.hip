@@ -272,7 +272,7 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
         if (d_far_ctx && d_far_ctx != ctx->lms_ctx_far)
             KCHECK(hipMemcpyAsync(ctx->lms_ctx_far, d_far_ctx, m_far * 4, hipMemcpyDeviceToDevice, ctx->stream));
         else if (!d_far_ctx) // no context words came along: gather them all; nothing is known about ties either, so all are tainted
-            KCHECK(hipMemsetD32Async((hipDeviceptr_t)ctx->lms_ctx_far, (int)KISS_CTX_TAINT, m_far, ctx->stream));
+            KTRY(kiss_fill_u32(ctx, ctx->lms_ctx_far, KISS_CTX_TAINT, m_far)); // (a kernel: see kiss_fill_u32)
     }
     if (near_count && d_near_pos != ctx->lms_pos + m_far) // kiss_place_lms reads the near-end suffixes as the tail of the ascending list
         KCHECK(hipMemcpyAsync(ctx->lms_pos + m_far, d_near_pos, near_count * 4, hipMemcpyDeviceToDevice, ctx->stream));

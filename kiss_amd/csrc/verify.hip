@@ -187,10 +187,8 @@ extern "C" int kiss_hip_ctx_verify_sa_dev(kiss_hip_ctx *ctx, const uint8_t *d_S,
             break;
         }
         (void)hipEventRecord(e0, st);
-        if (hipMemsetAsync(bitmap, 0, c_off_words * 4 + VC * 8, st) != hipSuccess) {
-            rc = KISS_HIP_E_HIP;
-            break;
-        }
+        ctx->stream = st;
+        if ((rc = kiss_zero_u32(ctx, bitmap, c_off_words + VC * 2))) break; // (a kernel, not hipMemsetAsync: see kiss_fill_u32)
         const unsigned long long big = ~0ull;
         if (hipMemcpyAsync(&c[3], &big, 8, hipMemcpyHostToDevice, st) != hipSuccess) {
             rc = KISS_HIP_E_HIP;
