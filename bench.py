@@ -487,7 +487,7 @@ def assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof
                              "list, gather of the sorted pieces, induction on rank 0)" % (world, "" if world == 1 else "s"))
                             if sharded else "1 text per GPU (independent replicas)"),
             "lms": last_stats["m"], "lms_rounds": last_stats["lms_rounds"],
-            "tied_after_round0_item_rounds": last_stats["sort_item_rounds"] - last_stats["m"],
+            "tied_after_round0_item_rounds": max(0, last_stats["sort_item_rounds"] - last_stats["m"]),  # (this rank's share)
             "big_segment_item_rounds": last_stats["big_item_rounds"],
             "workspace_bytes": workspace_bytes,
             "induce_passes": last_stats["induce_passes"],

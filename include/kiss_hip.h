@@ -16,7 +16,8 @@
  * Conventions: every function returns 0 (KISS_HIP_OK) or a negative kiss_hip_status.
  * No exceptions cross the ABI.  Host buffers are owned by the caller.  Device
  * workspace is owned by a kiss_hip_ctx.  A ctx is bound to one HIP device and must
- * not be used from two threads at once; distinct ctxs are independent.
+ * not be used from two threads at once; distinct ctxs are independent (the device phases of two sorts on ONE device
+ * queue up behind each other -- DESIGN.md 4.2 --, transfers and queries overlap).
  */
 #ifndef KISS_HIP_H
 #define KISS_HIP_H

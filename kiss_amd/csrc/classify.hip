@@ -394,6 +394,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
 {
     if (win_hi > n) win_hi = n;
     if (win_lo > win_hi) win_lo = win_hi;
+    ctx->lms_pos_complete = win_lo == 0 && win_hi == n; // (the exchange of a sharded run overwrites the list anyway)
     const uint64_t words = div_up(n, 32);
     const uint64_t tiles = div_up(words, CL_THREADS);
     if (tiles > ctx->n_tiles_cap) return KINTERNAL();

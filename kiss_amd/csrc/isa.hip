@@ -283,28 +283,49 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window_write(const uint64_t
                                                                  uint64_t r_words, uint32_t *__restrict__ rank)
 {
     __shared__ uint32_t win[1 << RW_SHIFT];
-    const uint32_t sub = blockIdx.x >> 1, half = blockIdx.x & 1u; // sub-bin over all level-1 bins
-    const uint64_t idx0 = ((uint64_t)sub << L2_SHIFT) + ((uint64_t)half << RW_SHIFT);
-    if (idx0 >= r_words) return;
-    for (uint32_t i = threadIdx.x; i < (1u << RW_SHIFT) / 4; i += RW_THREADS)
-        reinterpret_cast<uint4 *>(win)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    __syncthreads();
+    const uint32_t sub = blockIdx.x; // sub-bin over all level-1 bins; its two windows one after the other: the pairs
+                                     // (~300 KB) come out of L2 the second time
     const uint32_t lo = bt[sub], hi = bt[sub + 1];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += RW_THREADS) {
-        const uint64_t v = pairs[i];
-        const uint32_t idx = (uint32_t)(v >> 32);
-        if (((idx >> RW_SHIFT) & 1u) == half) win[idx & ((1u << RW_SHIFT) - 1u)] = (uint32_t)v;
-    }
-    __syncthreads();
-    const uint64_t left = r_words - idx0;
-    const uint32_t cnt = left < (1ull << RW_SHIFT) ? (uint32_t)left : (1u << RW_SHIFT);
-    for (uint32_t i = threadIdx.x * 4; i < cnt; i += RW_THREADS * 4) {
-        if (i + 4 <= cnt) {
-            *reinterpret_cast<uint4 *>(rank + idx0 + i) = *reinterpret_cast<const uint4 *>(win + i);
-        } else {
-            for (uint32_t e = i; e < cnt; e++) rank[idx0 + e] = win[e];
+    for (uint32_t half = 0; half < 2; half++) {
+        const uint64_t idx0 = ((uint64_t)sub << L2_SHIFT) + ((uint64_t)half << RW_SHIFT);
+        if (idx0 >= r_words) return;
+        for (uint32_t i = threadIdx.x; i < (1u << RW_SHIFT) / 4; i += RW_THREADS)
+            reinterpret_cast<uint4 *>(win)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        __syncthreads();
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += RW_THREADS) {
+            const uint64_t v = pairs[i];
+            const uint32_t idx = (uint32_t)(v >> 32);
+            if (((idx >> RW_SHIFT) & 1u) == half) win[idx & ((1u << RW_SHIFT) - 1u)] = (uint32_t)v;
         }
+        __syncthreads();
+        const uint64_t left = r_words - idx0;
+        const uint32_t cnt = left < (1ull << RW_SHIFT) ? (uint32_t)left : (1u << RW_SHIFT);
+        for (uint32_t i = threadIdx.x * 4; i < cnt; i += RW_THREADS * 4) {
+            if (i + 4 <= cnt) {
+                *reinterpret_cast<uint4 *>(rank + idx0 + i) = *reinterpret_cast<const uint4 *>(win + i);
+            } else {
+                for (uint32_t e = i; e < cnt; e++) rank[idx0 + e] = win[e];
+            }
+        }
+        __syncthreads(); // the window is cleared again next
     }
+}
+
+// The same table without the ascending list (the multi-device entry: device 0 holds the gathered sorted list, but only its
+// own slice of the ascending one): count the list's indexes per sub-bin -- one LDS histogram per workgroup over all
+// sub-bins (<= 32 768 of them: 128 KiB), its non-zero counts added to the table -- and scan.
+constexpr int BH_THREADS = 1024;
+__global__ __launch_bounds__(BH_THREADS) void k_lms_bounds_hist(const uint32_t *__restrict__ L, uint64_t m, uint32_t subs,
+                                                               uint32_t *__restrict__ bt) // bt[1 + s] += #indexes in sub-bin s
+{
+    __shared__ uint32_t h[32768];
+    for (uint32_t i = threadIdx.x; i < subs; i += BH_THREADS) h[i] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BH_THREADS + threadIdx.x; i < m; i += (uint64_t)gridDim.x * BH_THREADS)
+        atomicAdd(&h[(L[i] >> 1) >> L2_SHIFT], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < subs; i += BH_THREADS)
+        if (h[i]) atomicAdd(&bt[1 + i], h[i]);
 }
 
 __global__ __launch_bounds__(256) void k_rank_direct(const uint32_t *__restrict__ L, uint64_t count,
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(256) void k_rank_direct(const uint32_t *__restrict_
 }
 } // namespace
 
-// L: the m LMS positions in sorted order; lms_asc: the same positions ascending.  rank: (n >> 1) + 1 words, every one of
+// L: the m LMS positions in sorted order; lms_asc: the same positions ascending (or null: the table is counted from L).  rank: (n >> 1) + 1 words, every one of
 // them written (0xFFFFFFFF where no LMS position maps to it).
 // pairs1, pairs2: m u64 of scratch each; small: 256 KiB + 64 KiB per level-1 bin (bin cursors, bounds table, tile table:
 // <= 8.3 MiB).
@@ -339,15 +360,32 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
     if (512ull * CUR_STRIDE + sub_total + 1 + bins + 1 + bins * 256 * CUR_STRIDE > small_words) return KINTERNAL();
     uint32_t *cursor = small;                     // 2 x 256 strided cursors
     uint32_t *bt = small + 512 * CUR_STRIDE;      // sub_total + 1 entries
-    {
+    if (lms_asc) {
         KTimer t(ctx, KISS_HIP_K_ISA, m);
         hipLaunchKernelGGL(k_lms_bounds, dim3((unsigned)div_up(sub_total + 1, 256)), dim3(256), 0, ctx->stream, lms_asc, m,
                            sub_total + 1, bt);
         KCHECK(hipGetLastError());
+    } else { // counts per sub-bin, then their running sums (bt[0] = 0)
+        if (sub_total > 32768) return KINTERNAL();
+        KTRY(kiss_zero_u32(ctx, bt, sub_total + 1));
+        {
+            KTimer t(ctx, KISS_HIP_K_ISA, m);
+            const uint64_t wgs = div_up(m, (uint64_t)BH_THREADS * 64);
+            hipLaunchKernelGGL(k_lms_bounds_hist, dim3((unsigned)(wgs < 1024 ? wgs : 1024)), dim3(BH_THREADS), 0, ctx->stream, L, m,
+                               sub_total, bt);
+            KCHECK(hipGetLastError());
+        }
+        // inclusive running sums in place: an exclusive scan of bt[1 ..] shifted by one entry would need a second array;
+        // the table is small -- scan it on the host while it is being fetched anyway (below)
     }
     std::vector<uint32_t> h_bt(sub_total + 1);
     KCHECK(hipMemcpyAsync(h_bt.data(), bt, (sub_total + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     KCHECK(hipStreamSynchronize(ctx->stream));
+    if (!lms_asc) { // counts -> bounds, and back to the device
+        for (uint32_t i = 1; i <= sub_total; i++) h_bt[i] += h_bt[i - 1];
+        KCHECK(hipMemcpyAsync(bt, h_bt.data(), (sub_total + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        KCHECK(hipStreamSynchronize(ctx->stream));
+    }
     if (h_bt[sub_total] != m) return KINTERNAL();
     KTRY(kiss_zero_u32(ctx, cursor, 256 * CUR_STRIDE));
     {
@@ -374,7 +412,7 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
     if (tiles)
         hipLaunchKernelGGL(k_rank_partition_all, dim3(tiles), dim3(IB_THREADS), 0, ctx->stream, pairs1, bt, d_tile0, (uint32_t)bins,
                            cursor2, pairs2);
-    hipLaunchKernelGGL(k_rank_window_write, dim3(2 * sub_total), dim3(RW_THREADS), 0, ctx->stream, pairs2, bt, idx_total, rank);
+    hipLaunchKernelGGL(k_rank_window_write, dim3(sub_total), dim3(RW_THREADS), 0, ctx->stream, pairs2, bt, idx_total, rank);
     KCHECK(hipGetLastError());
     KCHECK(hipStreamSynchronize(ctx->stream)); // h_tile0 goes out of scope
     return KISS_HIP_OK;

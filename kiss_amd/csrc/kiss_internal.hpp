@@ -63,6 +63,7 @@ struct kiss_hip_ctx {
     uint32_t *d_counts = nullptr;  // 16 x u32: cnt[4], cntS[4], cntLMS[4], far_lms, spare
     // LMS arrays
     uint32_t *lms_pos = nullptr;   // ascending LMS positions (kept for stage output)
+    bool lms_pos_complete = false; // ... all m of them (a whole-text classification on this ctx: not in the multi-device entry)
     uint64_t *keyA = nullptr, *keyB = nullptr;
     uint32_t *posA = nullptr, *posB = nullptr;
     uint32_t *segA = nullptr, *segB = nullptr;

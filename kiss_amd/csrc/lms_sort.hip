@@ -2307,7 +2307,8 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             if ((rc = fc_count<FC_HEADS>(ctx, reinterpret_cast<const uint64_t *>(heads), nullptr, m, 0, 0, d_total))) break;
         }
         // ranks (entries without an LMS position read as 0xFFFFFFFF)
-        if ((rc = kiss_rank_build_lms(ctx, L, ctx->lms_pos, m, n, R, pairs1, ctx->keyA, reinterpret_cast<uint32_t *>(ctx->keyB),
+        if ((rc = kiss_rank_build_lms(ctx, L, ctx->lms_pos_complete ? ctx->lms_pos : (const uint32_t *)nullptr, m, n, R, pairs1, ctx->keyA,
+                                      reinterpret_cast<uint32_t *>(ctx->keyB),
                                       2 * ctx->m_cap)))
             break;
         uint32_t *P = ctx->posA, *P2 = ctx->posB;

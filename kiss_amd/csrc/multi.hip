@@ -340,8 +340,18 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
             mc->stats.m = ctx->m;
             rc = kiss_place_lms(ctx, n, sh->k, sh->depth);
         }
+        // exact order: the doubling over the LMS suffixes before the induction, as in the one-device path (api.hip: sort_dev);
+        // tie flags by comparison (the sort's own flags stayed on the devices that sorted), bin sizes of the rank array
+        // counted from the gathered list (the ascending list is spread over the devices)
+        bool lms_resolved = false;
+        if (!rc && sh->h0 && !getenv("KISS_HIP_NO_LMS_EXACT")) {
+            ctx->lms_pos_complete = false;
+            ctx->hfar = nullptr;
+            rc = kiss_lms_exact_refine(ctx, n, sh->h0, sh->d_SA, &lms_resolved);
+        }
         if (!rc) rc = kiss_induce(ctx, n, sh->d_SA);
-        if (!rc && sh->h0) rc = kiss_exact_refine(ctx, n, sh->h0, sh->d_SA);
+        if (!rc && sh->h0 && !lms_resolved) rc = kiss_exact_refine(ctx, n, sh->h0, sh->d_SA);
+        if (!rc && sh->h0 && lms_resolved) ctx->stats.refine_form = 1;
         if (!rc) rc = sync();
         if (!rc) rc = kiss_radix_check(ctx);
         fail(rc);

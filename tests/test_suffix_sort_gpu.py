@@ -642,6 +642,14 @@ def test_exact_order_lms_level_doubling(oracle, monkeypatch, shape):
         # k-ordered calls are untouched by any of this
         assert np.array_equal(c.suffix_sort(S, 256), oracle.suffix_sort(S, 256))
         assert c.stats()["refine_form"] == 0
+    # the multi-device entry runs the same doubling on device 0, over the gathered list: tie flags by comparison, the bin
+    # sizes of the rank array counted from the list (no device holds the whole ascending list)
+    for direct_max in (None, "1000"):
+        if direct_max:
+            monkeypatch.setenv("KISS_HIP_ISA_DIRECT_MAX", direct_max)
+        with kiss_amd.MultiContext([0, 0], max_n=S.size) as mc:
+            assert np.array_equal(mc.suffix_sort(S, 0xFFFFFFFF, algo=1), want), (shape, direct_max)
+    monkeypatch.delenv("KISS_HIP_ISA_DIRECT_MAX", raising=False)
 
 
 @pytest.mark.parametrize("shape", ["tandem", "near_end_ties", "all_tied", "genome"])
