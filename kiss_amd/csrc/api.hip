@@ -40,6 +40,30 @@ void ktimer_collect(kiss_hip_ctx *ctx)
     ctx->ev_used = 0;
 }
 
+static std::mutex &kiss_launch_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+static bool kiss_lock_launches()
+{
+    static const bool on = getenv("KISS_HIP_LOCK_LAUNCHES") != nullptr;
+    return on;
+}
+bool kiss_sync_launches()
+{
+    static const bool on = getenv("KISS_HIP_SYNC_LAUNCHES") != nullptr;
+    return on;
+}
+KissLaunchGuard::KissLaunchGuard() : held(kiss_lock_launches())
+{
+    if (held) kiss_launch_mutex().lock();
+}
+KissLaunchGuard::~KissLaunchGuard()
+{
+    if (held) kiss_launch_mutex().unlock();
+}
+
 // one lock per device: see sort_dev (also taken stage by stage by the multi-device entry when a device is listed twice)
 std::mutex &kiss_device_mutex(int device)
 {

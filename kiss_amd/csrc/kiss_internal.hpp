@@ -7,6 +7,28 @@
 #include <vector>
 #include "../../include/kiss_hip.h"
 
+// Experiment hook (KISS_HIP_LOCK_LAUNCHES=1, read once per process): every kernel launch of this library under one
+// process-wide lock -- to tell a fault of concurrent LAUNCHES from two host threads from one of concurrent EXECUTION of two
+// contexts' kernels.
+struct KissLaunchGuard {
+    bool held;
+    KissLaunchGuard();
+    ~KissLaunchGuard();
+};
+// second hook (KISS_HIP_SYNC_LAUNCHES=1): the launching thread waits for its stream after every launch -- no two kernels
+// of one context can overlap then, those of two contexts still can
+bool kiss_sync_launches();
+#define KISS_ARG4_(a, b, c, d, ...) d
+#ifdef hipLaunchKernelGGL
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                                                            \
+    do {                                                                                                               \
+        KissLaunchGuard kiss_launch_guard_;                                                                            \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                                                         \
+        if (kiss_sync_launches()) (void)hipStreamSynchronize(KISS_ARG4_(__VA_ARGS__, 0, 0, 0, 0));                     \
+    } while (0)
+#endif
+
 #define KISS_EMPTY_CTX 1u      // context word with no bases left (marker bit only)
 #define KISS_CTX_BASES 15u     // bases carried in a 32-bit context word
 // Bit 31 of a context word (15 bases + marker use bits 0..30): "taint".  Set by the LMS sort / placement on every LMS
