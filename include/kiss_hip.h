@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KISS_HIP_VERSION 102 /* 0.1.2: refine_form in kiss_hip_stats (the former reserved word) */
+#define KISS_HIP_VERSION 102 /* 0.1.2: refine_form in kiss_hip_stats (the former reserved word), kiss_hip_stage_induce_exact */
 
 typedef enum kiss_hip_status {
     KISS_HIP_OK = 0,
@@ -291,6 +291,13 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
 int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
                           const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
                           const uint64_t counts12[12], uint32_t *d_SA, void *stream);
+/* stage_induce_exact: stage_induce for a list the stages have ordered by h0 bases (k = h0), with the exact-order finish of
+ * kiss2_suffix_array_dna in front of the induction: rank doubling over the LMS suffixes, then ONE induction
+ * (kiss2_core.hpp:835-886).  *exact_out = 1: d_SA is the exact suffix array; 0: it is h0-ordered and stage_refine_exact
+ * has to finish the job (texts whose LMS suffixes are further apart than any window: DESIGN.md 2.3). */
+int kiss_hip_stage_induce_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, const uint32_t *d_far_sorted,
+                                const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                                const uint64_t counts12[12], uint32_t *d_SA, void *stream, int *exact_out);
 /* stage_refine_exact: turns the h0-ordered suffix array of the text packed by stage_classify (h0 = 512, say: the output of the
  * stages run with k = h0) into the exact suffix array by rank doubling over the tied suffixes -- what
  * kiss2_suffix_array_dna's prefix doubling yields for k = -1 (kiss2_core.hpp:728-797, 835-886).  Needs n >= 4 h0 + 1024. */

@@ -154,6 +154,8 @@ def load():
     lib.kiss_hip_stage_partition.argtypes = [vp, vp, vp, u64, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]
     lib.kiss_hip_stage_sort.argtypes = [vp, vp, vp, u64, u64, ctypes.c_uint32, vp, vp, vp]
     lib.kiss_hip_stage_induce.argtypes = [vp, u64, ctypes.c_uint32, vp, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp]
+    lib.kiss_hip_stage_induce_exact.argtypes = [vp, u64, ctypes.c_uint32, vp, vp, u64, vp, u64, ctypes.POINTER(u64 * 12), vp, vp,
+                                                ctypes.POINTER(ctypes.c_int)]
     lib.kiss_hip_stage_refine_exact.argtypes = [vp, u64, ctypes.c_uint32, vp, vp]
     lib.kiss_hip_stage_refine_exact.restype = ctypes.c_int
     lib.kiss_hip_fmi_query_batch_dev.argtypes = [
@@ -205,7 +207,7 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_fmi_query_batch_dev", "kiss_hip_fmi_build_dev",
     "kiss_hip_debug_radix_sort", "kiss_hip_debug_scan_u32",
     "kiss_hip_stage_classify", "kiss_hip_stage_local_lms", "kiss_hip_stage_key_hist", "kiss_hip_stage_partition",
-    "kiss_hip_stage_sort", "kiss_hip_stage_induce", "kiss_hip_stage_refine_exact",
+    "kiss_hip_stage_sort", "kiss_hip_stage_induce", "kiss_hip_stage_induce_exact", "kiss_hip_stage_refine_exact",
     "kiss_hip_fmi_sizes_for", "kiss_hip_fmi_build_host", "kiss_hip_fmi_query_batch_host",
     "kiss_hip_file_size", "kiss_hip_ctx_parse_text_dev", "kiss_hip_ctx_load_text_file", "kiss_hip_copy_to_host",
     "kiss_hip_free_dev", "kiss_hip_alloc_dev", "kiss_hip_suffix_sort_u8", "kiss_hip_ctx_suffix_sort_u8_dev",

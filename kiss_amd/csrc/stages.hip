@@ -251,9 +251,9 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     return KISS_HIP_OK;
 }
 
-int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
-                          const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
-                          const uint64_t counts12[12], uint32_t *d_SA, void *stream)
+static int stage_induce_impl(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint32_t exact_h0, const uint32_t *d_far_sorted,
+                             const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                             const uint64_t counts12[12], uint32_t *d_SA, void *stream, int *exact_out)
 {
     if (!ctx || !counts12 || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID;
     if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
@@ -282,10 +282,39 @@ int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint3
     ctx->stats.m = m;
     const uint64_t depth = depth_of(n, k);
     KTRY(kiss_place_lms(ctx, n, k, depth));
+    bool resolved = false;
+    if (exact_h0 && !getenv("KISS_HIP_NO_LMS_EXACT")) {
+        // the gathered list is h0-ordered: exact order of the LMS suffixes by rank doubling before the induction, as in the
+        // one-device path (api.hip: sort_dev); tie flags by comparison, bin sizes of the rank array counted from the list
+        ctx->lms_pos_complete = false;
+        ctx->hfar = nullptr;
+        KTRY(kiss_lms_exact_refine(ctx, n, exact_h0, d_SA, &resolved));
+    }
     KTRY(kiss_induce(ctx, n, d_SA));
     KTRY(kiss_radix_check(ctx));
+    if (resolved) ctx->stats.refine_form = 1;
+    if (exact_out) *exact_out = resolved ? 1 : 0;
     ktimer_collect(ctx);
     return KISS_HIP_OK;
+}
+
+int kiss_hip_stage_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *d_far_sorted,
+                          const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                          const uint64_t counts12[12], uint32_t *d_SA, void *stream)
+{
+    return stage_induce_impl(ctx, n, k, 0, d_far_sorted, d_far_ctx, m_far, d_near_pos, near_count, counts12, d_SA, stream,
+                             nullptr);
+}
+
+int kiss_hip_stage_induce_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, const uint32_t *d_far_sorted,
+                                const uint32_t *d_far_ctx, uint64_t m_far, const uint32_t *d_near_pos, uint64_t near_count,
+                                const uint64_t counts12[12], uint32_t *d_SA, void *stream, int *exact_out)
+{
+    if (!exact_out) return KISS_HIP_E_INVALID;
+    *exact_out = 0;
+    if (h0 < 32 || n < 4ull * h0 + 1024) return KISS_HIP_E_UNSUPPORTED;
+    return stage_induce_impl(ctx, n, h0, h0, d_far_sorted, d_far_ctx, m_far, d_near_pos, near_count, counts12, d_SA, stream,
+                             exact_out);
 }
 
 } // extern "C"

@@ -157,6 +157,20 @@ class GpuBackend:
         if SA is None:
             SA = torch.empty(self.n + 1, dtype=torch.int32, device=self.dev)
         c = (ctypes.c_uint64 * 12)(*[int(x) for x in counts12])
+        self.last_induce_exact = False
+        if getattr(self, "exact_h0", 0):
+            # the list is exact_h0-ordered and the caller wants exact order: rank doubling over the LMS suffixes, then the
+            # induction (kiss_hip_stage_induce_exact); whether that settled everything is left in last_induce_exact
+            done = ctypes.c_int(0)
+            _check(self.lib.kiss_hip_stage_induce_exact(self.ctx._ctx, self.n, int(self.exact_h0),
+                                                        ctypes.c_void_p(far_all.data_ptr()),
+                                                        ctypes.c_void_p(far_ctx.data_ptr()) if far_ctx is not None else None,
+                                                        int(far_all.numel()), ctypes.c_void_p(near_all.data_ptr()),
+                                                        int(near_all.numel()), ctypes.byref(c), ctypes.c_void_p(SA.data_ptr()),
+                                                        None, ctypes.byref(done)),
+                   "kiss_hip_stage_induce_exact", self.ctx._ctx)
+            self.last_induce_exact = bool(done.value)
+            return SA
         _check(self.lib.kiss_hip_stage_induce(self.ctx._ctx, self.n, self.k, ctypes.c_void_p(far_all.data_ptr()),
                                               ctypes.c_void_p(far_ctx.data_ptr()) if far_ctx is not None else None,
                                               int(far_all.numel()), ctypes.c_void_p(near_all.data_ptr()),
@@ -438,11 +452,13 @@ def sharded_suffix_sort(backend, n, group=None, SA=None, timings=None):
                 raise RuntimeError("sharded exact sort: ties too deep on a text too short for the doubling form")
             k_exact = backend.k
             backend.k = EXACT_H0
+            backend.exact_h0 = EXACT_H0  # (rank 0's induce: exact order of the LMS suffixes first, where the backend can)
             try:
                 out = sharded_suffix_sort(backend, n, group=group, SA=SA, timings=timings)
             finally:
                 backend.k = k_exact
-            if r == 0:
+                backend.exact_h0 = 0
+            if r == 0 and not getattr(backend, "last_induce_exact", False):
                 out = backend.refine_exact(out, EXACT_H0)
             comm.barrier()
             return out
