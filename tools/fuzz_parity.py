@@ -37,6 +37,8 @@ while time.time() - t0 < budget:
     kind = kinds[int(rng.integers(0, len(kinds)))]
     kk = [1, 2, 31, 32, 33, 124, 125, 126, 249, 250, 256, 375, 400, 1000, 0xFFFFFFFF, 0xFFFFFFFF]
     k = int(kk[int(rng.integers(0, len(kk)))])
+    if os.environ.get("FUZZ_EXACT_ONLY"):  # every case through PREFIX_DOUBLING at k = -1 (the LMS-level doubling and its give-up paths)
+        k = 0xFFFFFFFF
     # the oracle's exact comparator is quadratic on long repeats: those cases are checked with the linear-time
     # suffix-array test instead (the exact suffix array is unique, so the test is a complete oracle)
     linear = k == 0xFFFFFFFF and kind not in ("iid", "genome")
@@ -69,6 +71,8 @@ while time.time() - t0 < budget:
     S = np.ascontiguousarray(S, dtype=np.uint8)
     n = int(S.size)
     algo = int(rng.integers(0, 2)) if k == 0xFFFFFFFF else 0
+    if os.environ.get("FUZZ_EXACT_ONLY"):
+        algo = 1
     try:
         sa = ctx.suffix_sort(S, k, algo=algo)
     except Exception as e:  # noqa: BLE001
