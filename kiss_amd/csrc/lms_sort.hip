@@ -2196,6 +2196,11 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
     const uint64_t m = ctx->m;
     const unsigned T = LS_THREADS;
     const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    // experiment hook: bit i set = the host waits for the stream at sync point i of every round
+    const unsigned sync_points = getenv("KISS_HIP_LX_SYNC_POINTS") ? (unsigned)strtoul(getenv("KISS_HIP_LX_SYNC_POINTS"), nullptr, 0) : 0u;
+    auto sync_point = [&](unsigned i) {
+        if ((sync_points >> i) & 1u) (void)hipStreamSynchronize(ctx->stream);
+    };
     ctx->hmerged = nullptr;
     if (m < 2) {
         KTRY(kiss_merge_lms(ctx));
@@ -2356,8 +2361,10 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
                 hipLaunchKernelGGL(k_group_sort_small_lms, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, ctx->bkeyA, P, G, SS,
                                    dG, count, D, ctx->bkeyB, ctx->bposB, maxlen > SMALL_SEG ? F1 : nullptr, ctl);
             }
+            sync_point(0);
             if (maxlen > SMALL_SEG) {
                 if ((rc = kiss_scan_u64(ctx, F1, F2, count))) break;
+                sync_point(1);
                 hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
                 uint64_t bt;
                 if ((rc = read_u64(ctx, d_total, &bt))) break;
@@ -2377,11 +2384,14 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
                                            bb.pos[0], bb.seg[0], bidx);
                     }
                     int bres = 0;
+                    sync_point(2);
                     if ((rc = kiss_radix_sort(ctx, bb, nbig, 32, bits_for(nbigseg), &bres))) break;
+                    sync_point(3);
                     ctx->stats.big_item_rounds += nbig;
                     KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, nbig);
                     hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)div_up(nbig, T)), dim3(T), 0, ctx->stream, bb.key[bres],
                                        bb.pos[bres], bidx, nbig, ctx->bkeyB, ctx->bposB);
+                    sync_point(4);
                 }
             }
             const uint64_t *skey = ctx->bkeyB;
@@ -2389,6 +2399,7 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
             ctx->stats.doubling_rounds++;
             ctx->stats.sort_item_rounds += count;
             if ((rc = fc_count<FC_KEY_SEG>(ctx, skey, sseg, count, 32, 0, d_total))) break;
+            sync_point(5);
             // singletons retire into the list and the rank array; survivors are compacted (slots stay in index order)
             // (and take the context word of their own position along: the list entry they replace was another suffix's)
             if ((rc = fc_compact<FC_KEY_SEG, true>(ctx, skey, sseg, spos, S, count, 32, 0, P2, S2, G2, SS2, L, R, nullptr, nullptr,
