@@ -2227,6 +2227,12 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
     }
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     uint32_t *ctl = ctx->d_small + 8;
+    // the partition's pairs need 2 m words of the (n + 1)-word scratch, 8-byte aligned: a text with n/2 LMS suffixes in a
+    // buffer that starts on an odd word has one word too few -- the suffix-array form takes that call
+    if (((uintptr_t)scratch & 7) && 2 * m + 2 > n + 1) {
+        ctx->lms_merged = false;
+        return kiss_merge_lms(ctx);
+    }
     uint64_t *pairs1 = reinterpret_cast<uint64_t *>(((uintptr_t)scratch + 7) & ~(uintptr_t)7);
     uint32_t *bigpos0 = scratch, *bigpos1 = scratch + m; // (after the rank array is built: pairs1 is dead then)
 
