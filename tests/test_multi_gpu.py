@@ -162,6 +162,51 @@ class DeepTieBackend(OracleBackend):
         return torch.from_numpy(self.orc.suffix_sort(self.S, 0xFFFFFFFF).view(np.int32).copy())
 
 
+class DeepTieBackendExactInduce(DeepTieBackend):
+    """... whose rank-0 induction of the rerun delivers the exact order by itself (what kiss_hip_stage_induce_exact does when
+    the doubling over the LMS suffixes settles everything): refine_exact must not be called then"""
+
+    def induce(self, far_all, near_all, counts12, SA=None, far_ctx=None):
+        from kiss_amd import multi_gpu
+        self.last_induce_exact = False
+        if getattr(self, "exact_h0", 0):
+            assert self.exact_h0 == multi_gpu.EXACT_H0 and self.k == multi_gpu.EXACT_H0 and dist.get_rank() == 0
+            self.last_induce_exact = True
+            return torch.from_numpy(self.orc.suffix_sort(self.S, 0xFFFFFFFF).view(np.int32).copy())
+        return super().induce(far_all, near_all, counts12, SA, far_ctx=far_ctx)
+
+
+def _cpu_worker_deep_exact_induce(rank, world, port, n, deep_rank, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kiss_amd import multi_gpu
+        S = gen.genome_like(n, 12)
+        be = DeepTieBackendExactInduce(S, 0xFFFFFFFF, deep_rank)
+        sa = multi_gpu.sharded_suffix_sort(be, n)
+        assert be.k == 0xFFFFFFFF and getattr(be, "exact_h0", 0) == 0  # both restored after the rerun
+        if rank == 0:
+            from tests import oracle_binding
+            q.put(be.refined == 0 and bool(np.array_equal(sa.numpy().view(np.uint32),
+                                                          oracle_binding.load().suffix_sort(S, 0xFFFFFFFF))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exact_order_rerun_skips_refine_when_the_induction_is_exact_gloo_cpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_cpu_worker_deep_exact_induce, args=(r, 2, port, 8000, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def _cpu_worker_deep(rank, world, port, n, deep_rank, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
