@@ -120,6 +120,12 @@ enum {
 };
 
 int kiss_hip_version(void);
+/* 0 for the shipped library.  1 for the hooks build of the same sources (libkiss_hip_hooks.so, -DKISS_HIP_HOOKS): test
+ * infrastructure in which KISS_HIP_* environment variables switch A-B forms, tuning values, fault injection and tracing,
+ * re-read at the start of every call.  The shipped library looks at the environment once per context, in
+ * kiss_hip_ctx_create, and only for KISS_HIP_DEBUG (progress lines on stderr), KISS_HIP_XFER_THREADS and
+ * KISS_HIP_PREFAULT_THREADS (host-side copy / page-fault helper threads): no variable changes a result path. */
+int kiss_hip_has_hooks(void);
 const char *kiss_hip_strerror(int status);
 /* number of visible HIP devices (does not initialise a context) */
 int kiss_hip_device_count(int *count);

@@ -9,6 +9,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkiss_hip.so")
+# the hooks build of the same sources (-DKISS_HIP_HOOKS: environment switches read at every call, fault injection,
+# tracing -- kiss_amd/csrc/kiss_internal.hpp KissOpts).  Test infrastructure: only what asks for it (`load(hooks=True)`,
+# `Context(..., hooks=True)`, or KISS_AMD_LIB=hooks for a whole process) ever loads it.
+HOOKS_LIB_PATH = os.path.join(_HERE, "libkiss_hip_hooks.so")
 
 KISS_HIP_OK = 0
 KISS_HIP_E_INVALID, KISS_HIP_E_NO_DEVICE, KISS_HIP_E_HIP, KISS_HIP_E_NOMEM = -1, -2, -3, -4
@@ -93,19 +97,29 @@ class KissHipError(RuntimeError):
         super().__init__(msg)
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libkiss_hip.so; raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(hooks=None):
+    """Load libkiss_hip.so (hooks=True: libkiss_hip_hooks.so); raises (never falls back) when it is missing."""
+    if hooks is None:
+        hooks = os.environ.get("KISS_AMD_LIB", "") == "hooks"
+    hooks = bool(hooks)
+    if hooks in _libs:
+        return _libs[hooks]
+    path = HOOKS_LIB_PATH if hooks else LIB_PATH
+    # A-B harnesses (tools/ab_libs.sh, tools/rx_ab.sh) name a variant build of the default library by path instead of
+    # overwriting the shipped file
+    if not hooks and os.environ.get("KISS_AMD_LIB_PATH"):
+        path = os.environ["KISS_AMD_LIB_PATH"]
+    if not os.path.exists(path):
         raise ImportError(
-            "libkiss_hip.so not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C kiss_amd/csrc`; there is no CPU fallback" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "%s not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C kiss_amd/csrc`; there is no CPU fallback" % (os.path.basename(path), path))
+    lib = ctypes.CDLL(path)
+    lib.kiss_hip_has_hooks.restype = ctypes.c_int
+    if bool(lib.kiss_hip_has_hooks()) != hooks:
+        raise ImportError("%s is not the %s build" % (path, "hooks" if hooks else "default"))
     vp, u8p = ctypes.c_void_p, ctypes.c_void_p
     lib.kiss_hip_version.restype = ctypes.c_int
     lib.kiss_hip_strerror.restype = ctypes.c_char_p
@@ -190,7 +204,7 @@ def load():
                  "kiss_hip_multi_get_stats", "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_stage_view",
                  "kiss_hip_stage_reserve"):
         getattr(lib, name).restype = ctypes.c_int
-    _lib = lib
+    _libs[hooks] = lib
     return lib
 
 
@@ -215,4 +229,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_multi_create", "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32",
     "kiss_hip_multi_suffix_sort_dna_u32_dev", "kiss_hip_multi_get_stats", "kiss_hip_multi_ctx",
     "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters", "kiss_hip_debug_fail_alloc_over",
+    "kiss_hip_has_hooks",
 ]

@@ -40,6 +40,58 @@ void ktimer_collect(kiss_hip_ctx *ctx)
     ctx->ev_used = 0;
 }
 
+// ---- options (kiss_internal.hpp: KissOpts) ---------------------------------------------------------------
+static void kiss_opts_supported_from_env(KissOpts &o) // both builds, once per context
+{
+    o.debug = getenv("KISS_HIP_DEBUG") != nullptr;
+    if (const char *e = getenv("KISS_HIP_XFER_THREADS")) o.xfer_threads = atoi(e);
+    if (const char *e = getenv("KISS_HIP_PREFAULT_THREADS")) o.prefault_threads = atoi(e);
+}
+#ifdef KISS_HIP_HOOKS
+static bool env_on(const char *name) { return getenv(name) != nullptr; }
+static unsigned long long env_u64(const char *name, unsigned long long dflt)
+{
+    const char *e = getenv(name);
+    return e ? strtoull(e, nullptr, 0) : dflt;
+}
+void kiss_opts_refresh(kiss_hip_ctx *ctx)
+{
+    KissOpts o;
+    kiss_opts_supported_from_env(o);
+    if (const char *e = getenv("KISS_HIP_SYNC_READBACK")) o.sync_readback = atoi(e) != 0;
+    o.no_serialize = env_on("KISS_HIP_NO_SERIALIZE");
+    o.no_lms_exact = env_on("KISS_HIP_NO_LMS_EXACT");
+    o.heads_by_compare = env_on("KISS_HIP_LMS_HEADS_BY_COMPARE");
+    o.no_early_out = env_on("KISS_HIP_NO_EARLY_OUT");
+    o.no_pivot_rounds = env_on("KISS_HIP_NO_PIVOT_ROUNDS");
+    o.pivot_from_round2 = env_on("KISS_HIP_PIVOT_FROM_ROUND2");
+    o.pair_keys = env_on("KISS_HIP_PAIR_KEYS");
+    o.no_fc0_onepass = env_on("KISS_HIP_NO_FC0_ONEPASS");
+    o.no_pivot_ctx = env_on("KISS_HIP_NO_PIVOT_CTX");
+    o.no_taint = env_on("KISS_HIP_NO_TAINT");
+    o.isa_direct = env_on("KISS_HIP_ISA_DIRECT");
+    o.no_onesweep = env_on("KISS_HIP_NO_ONESWEEP");
+    o.merge_lms = env_on("KISS_HIP_MERGE_LMS");
+    o.no_small_alphabet = env_on("KISS_HIP_NO_SMALL_ALPHABET");
+    o.verify = env_on("KISS_HIP_VERIFY");
+    o.no_prefault = env_on("KISS_HIP_NO_PREFAULT");
+    o.doubling_h0 = (uint32_t)env_u64("KISS_HIP_DOUBLING_H0", 0);
+    o.tcap0 = env_u64("KISS_HIP_TCAP0", 0);
+    o.pivot_slots = (int)env_u64("KISS_HIP_PIVOT_SLOTS", 3);
+    o.small_seg = (uint32_t)env_u64("KISS_HIP_SMALL_SEG", 0);
+    o.near_merge_min = (uint32_t)env_u64("KISS_HIP_NEAR_MERGE_MIN", 4096);
+    o.induce_small_max = (uint32_t)env_u64("KISS_HIP_INDUCE_SMALL_MAX", 0);
+    o.collapse_cap = (uint32_t)env_u64("KISS_HIP_COLLAPSE_CAP", 0);
+    o.collapse_n = env_u64("KISS_HIP_COLLAPSE_N", 0);
+    o.fm_heavy = (uint32_t)env_u64("KISS_HIP_FM_HEAVY", 0);
+    o.fm_light = (uint32_t)env_u64("KISS_HIP_FM_LIGHT", 0);
+    o.isa_direct_max = env_u64("KISS_HIP_ISA_DIRECT_MAX", 0);
+    o.lx_sync_points = (unsigned)env_u64("KISS_HIP_LX_SYNC_POINTS", 0);
+    o.tie_trace = (unsigned)env_u64("KISS_HIP_TIE_TRACE", 0);
+    o.poison = (uint32_t)env_u64("KISS_HIP_POISON", 0);
+    if (const char *e = getenv("KISS_HIP_DUMP_PIVOT")) snprintf(o.dump_pivot, sizeof o.dump_pivot, "%s", e);
+    ctx->opts = o;
+}
 static std::mutex &kiss_launch_mutex()
 {
     static std::mutex m;
@@ -63,6 +115,7 @@ KissLaunchGuard::~KissLaunchGuard()
 {
     if (held) kiss_launch_mutex().unlock();
 }
+#endif
 
 // one lock per device: see sort_dev (also taken stage by stage by the multi-device entry when a device is listed twice)
 std::mutex &kiss_device_mutex(int device)
@@ -87,10 +140,7 @@ __global__ void k_publish(const uint32_t *__restrict__ src, uint32_t nwords, uin
 int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
 {
     if (nwords > 16) return KINTERNAL();
-    if (ctx->pub_mode < 0) {
-        const char *e = getenv("KISS_HIP_SYNC_READBACK");
-        ctx->pub_mode = (e && atoi(e) != 0) || !ctx->h_pub || !ctx->d_pub ? 0 : 1;
-    }
+    ctx->pub_mode = ctx->opts.sync_readback || !ctx->h_pub || !ctx->d_pub ? 0 : 1;
     if (ctx->pub_mode == 0) {
         KCHECK(hipMemcpyAsync(ctx->h_pinned, d_src, nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         KCHECK(hipStreamSynchronize(ctx->stream));
@@ -121,7 +171,7 @@ int kiss_readback(kiss_hip_ctx *ctx, const void *d_src, uint32_t nwords)
 }
 
 bool kiss_host_is_pinned(const void *p); // xfer.hip
-void *kiss_prefault_start(void *p, uint64_t bytes);
+void *kiss_prefault_start(kiss_hip_ctx *ctx, void *p, uint64_t bytes);
 void kiss_prefault_join(void *handle);
 
 namespace {
@@ -134,6 +184,11 @@ int dmalloc(kiss_hip_ctx *ctx, T **p, uint64_t count)
     // fault-injection hook of tests/test_suffix_sort_gpu.py (kiss_hip_debug_fail_alloc_over): work arrays above this many
     // bytes "do not fit"; 0 = no limit.  No environment look-up per allocation in the shipped path.
     hipError_t e = ctx->fail_alloc_over && bytes > ctx->fail_alloc_over ? hipErrorOutOfMemory : hipMalloc(&q, bytes);
+#ifdef KISS_HIP_HOOKS
+    // KISS_HIP_POISON=<word>: a work array never starts out as zeros or as what its last owner left in it -- a kernel that
+    // reads an element nobody wrote in this call then gives a result that differs from the unpoisoned run's
+    if (e == hipSuccess && ctx->opts.poison) e = hipMemsetD32(q, (int)ctx->opts.poison, bytes / 4);
+#endif
     if (e != hipSuccess) {
         (void)hipGetLastError(); // (or the next launch check reports this failure as its own)
         ctx->last_hip_error = (int)e;
@@ -186,6 +241,9 @@ void free_all(kiss_hip_ctx *ctx)
         if (p) (void)hipFree(p);
     for (void *p : ctx->fm_pool)
         if (p) (void)hipFree(p);
+#ifdef KISS_HIP_HOOKS
+    if (ctx->tie_dbg) (void)hipFree(ctx->tie_dbg);
+#endif
     if (ctx->io_S) (void)hipFree(ctx->io_S);
     if (ctx->io_SA) (void)hipFree(ctx->io_SA);
     kiss_xfer_free(ctx);
@@ -211,7 +269,8 @@ int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_
 int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int algo, uint32_t *d_SA, void *stream)
 {
     if (!ctx) return KISS_HIP_E_INVALID;
-    if (getenv("KISS_HIP_NO_SERIALIZE")) return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
+    kiss_opts_refresh(ctx);
+    if (ctx->opts.no_serialize) return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
     std::lock_guard<std::mutex> lock(kiss_device_mutex(ctx->device));
     return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
 }
@@ -251,10 +310,7 @@ int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_
     uint32_t h0 = 0;
     if (algo == KISS_HIP_ALGO_PREFIX_DOUBLING) {
         h0 = KISS_EXACT_H0;
-        if (const char *e = getenv("KISS_HIP_DOUBLING_H0")) { // tuning hook: 32 <= h0
-            const int v = atoi(e);
-            if (v >= 32 && v <= (1 << 20)) h0 = (uint32_t)v;
-        }
+        if (ctx->opts.doubling_h0 >= 32 && ctx->opts.doubling_h0 <= (1u << 20)) h0 = ctx->opts.doubling_h0; // (hooks build: tuning)
         if (n < 4ull * h0 + 1024) h0 = 0;
         else {
             k = h0;
@@ -267,7 +323,7 @@ int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_
     for (auto &e : ev) KCHECK(hipEventCreate(&e));
     // exact order: the doubling runs over the LMS suffixes before the induction (kiss_lms_exact_refine); the suffix-array form
     // (kiss_exact_refine) finishes only what that leaves.  KISS_HIP_NO_LMS_EXACT=1 (A-B hook, read per call): the old order of things.
-    const bool lms_exact = getenv("KISS_HIP_NO_LMS_EXACT") == nullptr;
+    const bool lms_exact = !ctx->opts.no_lms_exact;
     int rc = KISS_HIP_OK;
     for (int attempt = 0; attempt < 2; attempt++) {
         (void)hipEventRecord(ev[0], ctx->stream);
@@ -277,7 +333,7 @@ int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_
         (void)hipEventRecord(ev[2], ctx->stream);
         ctx->hfar = nullptr;
         ctx->h_depth = h0;
-        if (h0 && lms_exact && ctx->m_far && !getenv("KISS_HIP_LMS_HEADS_BY_COMPARE")) { // (A-B hook, read per call)
+        if (h0 && lms_exact && ctx->m_far && !ctx->opts.heads_by_compare) {
             // the LMS sort notes which far suffix retires tied with its predecessor: one byte per far-list slot at the far
             // end of CTX (kiss_lms_exact_refine lays its rank array and the merged list's flags out from the near end)
             if ((rc = kiss_need_ctx_words(ctx))) break;
@@ -333,7 +389,11 @@ int sort_dev_unlocked(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_
         break;
     }
     if (rc != KISS_HIP_OK) (void)hipStreamSynchronize(ctx->stream);
+#ifdef KISS_HIP_HOOKS
+    kiss_tie_trace_report(ctx);
+#endif
     ctx->hfar = ctx->hmerged = nullptr;
+    ctx->h_depth = 0;
     ctx->stats.m = ctx->m;
     ktimer_collect(ctx);
     for (auto &e : ev) (void)hipEventDestroy(e);
@@ -369,7 +429,7 @@ int kiss_need_ctx_words(kiss_hip_ctx *ctx)
 
 int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
 {
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const bool dbg = ctx->opts.debug;
     const auto t_begin = std::chrono::steady_clock::now();
     free_lms_side(ctx);
     if (dbg)
@@ -420,10 +480,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
     // a caller that knows how many tied items it is about to handle says so: one allocation of the tied-segment arrays
     // instead of the default one followed by a regrow (large hipMallocs late in a process run at 20-30 GB/s)
     if (t_cap_wanted > t0) t0 = t_cap_wanted;
-    if (const char *e = getenv("KISS_HIP_TCAP0")) { // test hook: start small so that every growth path runs
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= 1 && v < t0) t0 = v;
-    }
+    if (ctx->opts.tcap0 >= 1 && ctx->opts.tcap0 < t0) t0 = ctx->opts.tcap0; // (hooks build: start small so that every growth path runs)
     if (dbg)
         fprintf(stderr, "[kiss_hip] lms_reserve(%llu): %.1f GB allocated, %.3f s so far\n", (unsigned long long)m_cap,
                 (double)ctx->lms_bytes / 1e9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
@@ -432,7 +489,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
 
 int kiss_tied_reserve(kiss_hip_ctx *ctx, uint64_t t_cap)
 {
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const bool dbg = ctx->opts.debug;
     const auto t_begin = std::chrono::steady_clock::now();
     free_tied(ctx);
     const auto t_freed = std::chrono::steady_clock::now();
@@ -485,6 +542,7 @@ int kiss_host_sort(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, 
                    int (*sort)(void *, const uint8_t *, uint32_t *), void *arg)
 {
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = ctx->own_stream;
     if (!ctx->io_S || !ctx->io_SA || ctx->io_cap < n) { // device-side copies of the caller's buffers: owned by the ctx, sized for max_n
         if (ctx->io_S) (void)hipFree(ctx->io_S);
@@ -513,13 +571,13 @@ int kiss_host_sort(kiss_hip_ctx *ctx, const uint8_t *S, uint64_t n, uint32_t k, 
     KTRY(kiss_xfer_h2d(ctx, ctx->io_S, S, n));
     const auto t1 = clk::now();
     // bounded order into a page-locked buffer: finished stretches of SA leave while the sweeps still run (xfer.hip)
-    const bool no_early = getenv("KISS_HIP_NO_EARLY_OUT") != nullptr; // A-B hook, read per call
+    const bool no_early = ctx->opts.no_early_out;
     const bool early = !no_early && n >= (1u << 22) && (uint64_t)k < n && kiss_host_is_pinned(SA);
     ctx->early_used = 0;
     ctx->early_bytes = 0;
     ctx->early_host_SA = early ? SA : nullptr;
     // a pageable destination: its page faults are taken by helper threads while the device sorts
-    void *prefault = kiss_host_is_pinned(SA) ? nullptr : kiss_prefault_start(SA, (n + 1) * sizeof(uint32_t));
+    void *prefault = kiss_host_is_pinned(SA) ? nullptr : kiss_prefault_start(ctx, SA, (n + 1) * sizeof(uint32_t));
     int rc = sort(arg, ctx->io_S, ctx->io_SA);
     ctx->early_host_SA = nullptr;
     (void)hipSetDevice(ctx->device);
@@ -607,6 +665,8 @@ int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, ui
     ctx->device = device;
     ctx->max_n = max_n;
     ctx->m_cap0 = lms_capacity ? lms_capacity + 4096 : 0;
+    kiss_opts_supported_from_env(ctx->opts); // the only look at the environment the shipped library ever takes
+    kiss_opts_refresh(ctx);                  // (hooks build: every switch)
     int rc = KISS_HIP_OK;
     do {
         if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
@@ -778,8 +838,23 @@ int kiss_hip_debug_radix_sort(kiss_hip_ctx *ctx, uint64_t *keys, uint32_t *pos, 
 int kiss_hip_debug_fail_alloc_over(kiss_hip_ctx *ctx, uint64_t bytes)
 {
     if (!ctx) return KISS_HIP_E_INVALID;
+#ifdef KISS_HIP_HOOKS
     ctx->fail_alloc_over = bytes;
     return KISS_HIP_OK;
+#else
+    (void)bytes;
+    return KISS_HIP_E_UNSUPPORTED; // fault injection exists in the hooks build only (libkiss_hip_hooks.so)
+#endif
+}
+
+/* 1 in the hooks build (libkiss_hip_hooks.so: environment switches, fault injection, tracing), 0 in the shipped one */
+int kiss_hip_has_hooks(void)
+{
+#ifdef KISS_HIP_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int kiss_hip_debug_scan_u32(kiss_hip_ctx *ctx, uint32_t *data, uint64_t count)

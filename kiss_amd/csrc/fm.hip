@@ -682,16 +682,10 @@ int kiss_hip_fmi_query_batch_dev(kiss_hip_ctx *ctx, const kiss_hip_fmi_view *fmi
                            (uint4 *)blocks.p);
         KCHECK(hipGetLastError());
     }
-    uint32_t fm_heavy = FM_HEAVY; // (KISS_HIP_FM_HEAVY: tuning hook, 16 .. 65536)
-    if (const char *e = getenv("KISS_HIP_FM_HEAVY")) {
-        const int v = atoi(e);
-        if (v >= 16 && v <= 65536) fm_heavy = (uint32_t)v;
-    }
-    uint32_t fm_light = fm_heavy;
-    if (const char *e = getenv("KISS_HIP_FM_LIGHT")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= (int)fm_heavy) fm_light = (uint32_t)v;
-    }
+    kiss_opts_refresh(ctx);
+    // (hooks build: the two tier thresholds can be swept, 16 .. 65536 and 1 .. fm_heavy)
+    const uint32_t fm_heavy = ctx->opts.fm_heavy >= 16 && ctx->opts.fm_heavy <= 65536 ? ctx->opts.fm_heavy : (uint32_t)FM_HEAVY;
+    const uint32_t fm_light = ctx->opts.fm_light >= 1 && ctx->opts.fm_light <= fm_heavy ? ctx->opts.fm_light : fm_heavy;
     KTRY(heavy.take(ctx, 0, (Q + 2) * 4)); // [0] = count, [1..] = pattern numbers
     KTRY(kiss_zero_u32(ctx, heavy.p, 1));
     KTRY(medium.take(ctx, 12, (Q + 2) * 4));

@@ -108,6 +108,9 @@ int kiss_hip_ctx_suffix_sort_u8_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint6
     if (!ctx || !d_SA || (n && !d_S)) return KISS_HIP_E_INVALID;
     if (n > KISS_HIP_MAX_N || n > ctx->max_n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
+    ctx->hfar = ctx->hmerged = nullptr;
+    ctx->h_depth = 0;
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     KTRY(kiss_workspace_ready(ctx));
     std::memset(&ctx->stats, 0, sizeof ctx->stats);
@@ -120,7 +123,7 @@ int kiss_hip_ctx_suffix_sort_u8_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint6
         KCHECK(hipStreamSynchronize(ctx->stream));
         return KISS_HIP_OK;
     }
-    if (n >= 4096 && !getenv("KISS_HIP_NO_SMALL_ALPHABET")) { // at most four distinct byte values: the DNA path
+    if (n >= 4096 && !ctx->opts.no_small_alphabet) { // at most four distinct byte values: the DNA path
         uint32_t *d_set = ctx->d_small + 48; // 9 words
         KTRY(kiss_zero_u32(ctx, d_set, 9));
         const uint64_t blocks = div_up(n, 64ull * (GA_THREADS / 64) * 64); // ~64 steps per wave

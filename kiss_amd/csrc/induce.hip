@@ -471,11 +471,8 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
     DstPos dp;
     for (int c = 0; c < 4; c++) dp.p[c] = sw.pos[c];
     ctx->stats.induce_passes++;
-    uint64_t small_max = SMALL_MAX;
-    if (const char *e = getenv("KISS_HIP_INDUCE_SMALL_MAX")) { // tuning hook
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= 64 && v <= (1ull << 20)) small_max = v;
-    }
+    const uint64_t small_max = ctx->opts.induce_small_max >= 64 && ctx->opts.induce_small_max <= (1u << 20) ? ctx->opts.induce_small_max
+                                                                                                           : (uint64_t)SMALL_MAX;
     if (N <= small_max) {
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
@@ -517,7 +514,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         KTRY(kiss_readback(ctx, ctx->d_small, 4));
         for (int c = 0; c < 4; c++) tot[c] = ctx->h_pinned[c];
     }
-    if (getenv("KISS_HIP_DEBUG"))
+    if (ctx->opts.debug)
         fprintf(stderr, "[kiss_hip] pass dir=%d beg=%lld N=%llu mask=%x self=%d -> %llu,%llu,%llu,%llu\n", sw.dir, (long long)beg,
                 (unsigned long long)N, emitmask, selfclass, (unsigned long long)tot[0], (unsigned long long)tot[1],
                 (unsigned long long)tot[2], (unsigned long long)tot[3]);
@@ -711,10 +708,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         const int tshift = wide ? 40 : 48; // step t in key bits [tshift, 64)
         const int rshift = tshift - 2;     // terminal key: class in bits 62..63, run in [rshift, 62)
         uint32_t cap = (uint32_t)(capq > rcap ? rcap : (capq < 1 ? 1 : capq));
-        if (const char *e = getenv("KISS_HIP_COLLAPSE_CAP")) { // test hook: force short steps
-            uint32_t f = (uint32_t)atoi(e);
-            if (f >= 1 && f < cap) cap = f;
-        }
+        if (ctx->opts.collapse_cap >= 1 && ctx->opts.collapse_cap < cap) cap = ctx->opts.collapse_cap; // (hooks build: force short steps)
         const unsigned grid = (unsigned)div_up(N, CH_THREADS);
         ctx->stats.induce_passes++;
         {
@@ -731,7 +725,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
         for (int x = 0; x < 4; x++) cnt[x] = ctx->h_pinned[x];
         const uint64_t ncap = ctx->h_pinned[4];
         const uint64_t E = ctx->h_pinned[5];
-        if (getenv("KISS_HIP_DEBUG"))
+        if (ctx->opts.debug)
             fprintf(stderr, "[kiss_hip] collapse dir=%d c=%u beg=%lld N=%llu cap=%u E=%llu ncap=%llu term=%u,%u,%u,%u\n", sw.dir, c,
                     (long long)beg, (unsigned long long)N, cap, (unsigned long long)E, (unsigned long long)ncap, cnt[0], cnt[1],
                     cnt[2], cnt[3]);
@@ -756,7 +750,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             hipLaunchKernelGGL(k_chain_write, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
                                ctx->pk, rb.key[res], rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
             KCHECK(hipGetLastError());
-            if (getenv("KISS_HIP_VERIFY")) {
+            if (ctx->opts.verify) {
                 int64_t lo = sw.dir > 0 ? dst : dst - (int64_t)E + 1, hi = sw.dir > 0 ? dst + (int64_t)E : dst + 1;
                 KTRY(verify_part(ctx, sw.SA, lo, hi, c, ctx->n, "collapse block"));
                 KTRY(checksum_pk(ctx, "after collapse block"));
@@ -885,12 +879,9 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
 
     uint64_t tot[4];
     bool done;
-    if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "induce start"));
-    uint64_t collapse_n = COLLAPSE_N;
-    if (const char *e = getenv("KISS_HIP_COLLAPSE_N")) { // tuning hook: rounds of at most this many items end in the closed form
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= 1024 && v <= (1ull << 26)) collapse_n = v;
-    }
+    if (ctx->opts.verify) KTRY(checksum_pk(ctx, "induce start"));
+    // rounds of at most this many items end in the closed form (hooks build: swept)
+    const uint64_t collapse_n = ctx->opts.collapse_n >= 1024 && ctx->opts.collapse_n <= (1ull << 26) ? ctx->opts.collapse_n : (uint64_t)COLLAPSE_N;
     uint64_t collapse_max = collapse_n < ctx->m_cap ? collapse_n : ctx->m_cap; // chain scratch: m_cap- and t_cap-sized arrays
     if (collapse_max > ctx->t_cap) collapse_max = ctx->t_cap;
 
@@ -921,8 +912,8 @@ int kiss_induce(kiss_hip_ctx *ctx, uint64_t n, uint32_t *d_SA)
         }
     }
 
-    if (getenv("KISS_HIP_VERIFY")) KTRY(checksum_pk(ctx, "L sweep end"));
-    if (getenv("KISS_HIP_VERIFY"))
+    if (ctx->opts.verify) KTRY(checksum_pk(ctx, "L sweep end"));
+    if (ctx->opts.verify)
         for (int c = 0; c < 4; c++) KTRY(verify_part(ctx, d_SA, (int64_t)start[c], (int64_t)(start[c] + cntL[c]), (uint32_t)c, n, "L-part"));
     // ---------------- S sweep: right to left ----------------
     Sweep S{ctx, d_SA, -1, {(int64_t)start[1] - 1, (int64_t)start[2] - 1, (int64_t)start[3] - 1, (int64_t)start[4] - 1}};

@@ -185,7 +185,7 @@ int kiss_isa_build(kiss_hip_ctx *ctx, const uint32_t *SA, uint64_t total, uint32
 {
     if (total == 0) return KISS_HIP_OK;
     uint64_t direct_max = 1ull << 25; // 128 MiB of isa: the plain scatter stays in the last-level cache
-    if (const char *e = getenv("KISS_HIP_ISA_DIRECT_MAX")) direct_max = strtoull(e, nullptr, 10); // test hook
+    if (ctx->opts.isa_direct_max) direct_max = ctx->opts.isa_direct_max; // (hooks build)
     if (total <= direct_max) {
         KTimer t(ctx, KISS_HIP_K_ISA, total);
         hipLaunchKernelGGL(k_isa_direct, dim3((unsigned)div_up(total, 256)), dim3(256), 0, ctx->stream, SA, total, isa);
@@ -345,7 +345,7 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
 {
     if (m == 0) return KISS_HIP_OK;
     uint64_t direct_max = 1ull << 25;
-    if (const char *e = getenv("KISS_HIP_ISA_DIRECT_MAX")) direct_max = strtoull(e, nullptr, 10); // test hook
+    if (ctx->opts.isa_direct_max) direct_max = ctx->opts.isa_direct_max; // (hooks build)
     const uint64_t idx_total = (n >> 1) + 1;
     if (m <= direct_max || m < (1ull << 16)) {
         KTimer t(ctx, KISS_HIP_K_ISA, m);

@@ -7,16 +7,61 @@
 #include <vector>
 #include "../../include/kiss_hip.h"
 
-// Experiment hook (KISS_HIP_LOCK_LAUNCHES=1, read once per process): every kernel launch of this library under one
-// process-wide lock -- to tell a fault of concurrent LAUNCHES from two host threads from one of concurrent EXECUTION of two
-// contexts' kernels.
+// ---- options ---------------------------------------------------------------------------------------------
+// The shipped library (default build) reads the environment ONCE, in kiss_hip_ctx_create, and only for the three
+// supported knobs below; no result path depends on a variable of the host application's environment.  Everything else --
+// A-B switches, tuning sweeps, fault injection, tracing -- exists only in the hooks build (-DKISS_HIP_HOOKS,
+// kiss_amd/libkiss_hip_hooks.so: what the tests that force the rare paths load), which re-reads the environment at
+// the start of every API call (kiss_opts_refresh) so that a test can flip a switch between two calls on one context.
+struct KissOpts {
+    // supported (both builds, read once per context)
+    bool debug = false;            // KISS_HIP_DEBUG: progress lines on stderr
+    int xfer_threads = 0;          // KISS_HIP_XFER_THREADS: copy threads of the host-pointer entry points (0 = default)
+    int prefault_threads = 0;      // KISS_HIP_PREFAULT_THREADS: helper threads that fault in a pageable destination (0 = default)
+    // hooks build only (the defaults are the product's behaviour)
+    bool sync_readback = false;    // KISS_HIP_SYNC_READBACK: counters by memcpy + stream synchronise instead of publish + spin
+    bool no_lms_exact = false;     // KISS_HIP_NO_LMS_EXACT: exact order by doubling over SA (the round-2 form)
+    bool heads_by_compare = false; // KISS_HIP_LMS_HEADS_BY_COMPARE: tie flags of the LMS-level doubling by comparison
+    bool no_early_out = false;     // KISS_HIP_NO_EARLY_OUT
+    bool no_pivot_rounds = false;  // KISS_HIP_NO_PIVOT_ROUNDS: 32-base rounds only
+    bool pivot_from_round2 = false;// KISS_HIP_PIVOT_FROM_ROUND2
+    bool pair_keys = false;        // KISS_HIP_PAIR_KEYS: gather the round's key for pairs as well
+    bool no_fc0_onepass = false;   // KISS_HIP_NO_FC0_ONEPASS: count + scan + compact after round 0
+    bool no_pivot_ctx = false;     // KISS_HIP_NO_PIVOT_CTX
+    bool no_taint = false;         // KISS_HIP_NO_TAINT: the suffix-array form compares every neighbour pair
+    bool isa_direct = false;       // KISS_HIP_ISA_DIRECT: inverse SA by plain random scatter
+    bool no_onesweep = false;      // KISS_HIP_NO_ONESWEEP: histogram + offsets + scatter radix passes
+    bool merge_lms = false;        // KISS_HIP_MERGE_LMS: the merged copy of the LMS list (round-1 form)
+    bool no_small_alphabet = false;// KISS_HIP_NO_SMALL_ALPHABET (general.hip)
+    bool verify = false;           // KISS_HIP_VERIFY: check sums and per-bucket checks inside the induction
+    bool no_prefault = false;      // KISS_HIP_NO_PREFAULT
+    bool no_serialize = false;     // KISS_HIP_NO_SERIALIZE: no per-device lock around the device phase of a sort
+    bool lock_launches = false;    // KISS_HIP_LOCK_LAUNCHES: every launch under one process-wide lock
+    bool sync_launches = false;    // KISS_HIP_SYNC_LAUNCHES: the launching thread waits for its stream after every launch
+    uint32_t doubling_h0 = 0;      // KISS_HIP_DOUBLING_H0 (0 = KISS_EXACT_H0)
+    uint64_t tcap0 = 0;            // KISS_HIP_TCAP0: first reservation of the tied-segment arrays (0 = default)
+    int pivot_slots = 3;           // KISS_HIP_PIVOT_SLOTS
+    uint32_t small_seg = 0;        // KISS_HIP_SMALL_SEG (0 = LMS_SMALL_SEG)
+    uint32_t near_merge_min = 4096;// KISS_HIP_NEAR_MERGE_MIN
+    uint32_t induce_small_max = 0; // KISS_HIP_INDUCE_SMALL_MAX (0 = default)
+    uint32_t collapse_cap = 0;     // KISS_HIP_COLLAPSE_CAP (0 = default)
+    uint64_t collapse_n = 0;       // KISS_HIP_COLLAPSE_N (0 = default)
+    uint32_t fm_heavy = 0, fm_light = 0; // KISS_HIP_FM_HEAVY / KISS_HIP_FM_LIGHT (0 = default)
+    uint64_t isa_direct_max = 0;   // KISS_HIP_ISA_DIRECT_MAX (0 = default)
+    unsigned lx_sync_points = 0;   // KISS_HIP_LX_SYNC_POINTS
+    unsigned tie_trace = 0;        // KISS_HIP_TIE_TRACE: flight recorder of the near-end tie marks (place.hip)
+    uint32_t poison = 0;           // KISS_HIP_POISON: fill every freshly allocated work array with this word (0 = off)
+    char dump_pivot[256] = {0};    // KISS_HIP_DUMP_PIVOT: file name prefix
+};
+struct kiss_hip_ctx;
+#ifdef KISS_HIP_HOOKS
+void kiss_opts_refresh(kiss_hip_ctx *ctx); // api.hip: re-reads the environment (hooks build only)
+// every kernel launch of the library under one process-wide lock / followed by a wait for its stream
 struct KissLaunchGuard {
     bool held;
     KissLaunchGuard();
     ~KissLaunchGuard();
 };
-// second hook (KISS_HIP_SYNC_LAUNCHES=1): the launching thread waits for its stream after every launch -- no two kernels
-// of one context can overlap then, those of two contexts still can
 bool kiss_sync_launches();
 #define KISS_ARG4_(a, b, c, d, ...) d
 #ifdef hipLaunchKernelGGL
@@ -27,6 +72,9 @@ bool kiss_sync_launches();
         hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                                                         \
         if (kiss_sync_launches()) (void)hipStreamSynchronize(KISS_ARG4_(__VA_ARGS__, 0, 0, 0, 0));                     \
     } while (0)
+#endif
+#else
+static inline void kiss_opts_refresh(kiss_hip_ctx *) {}
 #endif
 
 #define KISS_EMPTY_CTX 1u      // context word with no bases left (marker bit only)
@@ -40,7 +88,6 @@ bool kiss_sync_launches();
 #define KISS_STRIDE 125u       // KISS1_SPLIT_SORT_STRIDE_DNA, algo/sort/constant.hpp:29
 
 // ---- error plumbing -----------------------------------------------------------
-struct kiss_hip_ctx;
 #define KCHECK(call)                                   \
     do {                                               \
         hipError_t e__ = (call);                       \
@@ -63,6 +110,12 @@ struct kiss_hip_ctx;
 struct kiss_hip_ctx {
     int device = 0;
     int last_hip_error = 0;
+    KissOpts opts;
+#ifdef KISS_HIP_HOOKS
+    uint32_t *tie_dbg = nullptr; // place.hip: flight recorder of the near-end tie marks
+    bool tie_dbg_on = false;
+    uint32_t tie_dbg_E = 0, tie_dbg_k = 0;
+#endif
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream of the current call
     uint64_t max_n = 0;
@@ -252,6 +305,9 @@ int kiss_rank_build_lms(kiss_hip_ctx *ctx, const uint32_t *L, const uint32_t *lm
 int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *scratch, bool *resolved);
 // fills ctx->lmsP / ctx->lmsC from the far list and the near-end ranks of the last kiss_place_lms
 int kiss_merge_lms(kiss_hip_ctx *ctx);
+#ifdef KISS_HIP_HOOKS
+void kiss_tie_trace_report(kiss_hip_ctx *ctx); // place.hip
+#endif
 // near-end ranking, merge, context gather -> ctx->lmsP / ctx->lmsC
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth);
 // host <-> device legs of the host-pointer entry points (xfer.hip); both return after the bytes have arrived

@@ -1217,23 +1217,16 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint32_t *d_nbig = ctx->d_small + 8;
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
     const unsigned T = LS_THREADS;
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
-    const bool pivot_on = getenv("KISS_HIP_NO_PIVOT_ROUNDS") == nullptr; // test / A-B hook: 32-base rounds only
-    // from the first refinement round on; KISS_HIP_PIVOT_FROM_ROUND2 keeps the first one in the 32-base form (A-B hook)
-    const bool pivot_r1 = getenv("KISS_HIP_PIVOT_FROM_ROUND2") == nullptr;
+    const bool dbg = ctx->opts.debug;
+    const bool pivot_on = !ctx->opts.no_pivot_rounds; // (hooks build: 32-base rounds only)
+    // from the first refinement round on; pivot_from_round2 keeps the first one in the 32-base form (hooks build)
+    const bool pivot_r1 = !ctx->opts.pivot_from_round2;
     static const int pivot_den[3] = {4, 7, 11};
     unsigned pivot_rounds_done = 0;
-    int pivot_slots = 3; // deviations recorded per member and round (tuning hook: 1 .. 4)
-    if (const char *e = getenv("KISS_HIP_PIVOT_SLOTS")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 8) pivot_slots = v;
-    }
-    const bool no_pair_keys = getenv("KISS_HIP_PAIR_KEYS") == nullptr; // A-B hook: gather the round's key for pairs as well
-    uint32_t small_seg = LMS_SMALL_SEG;
-    if (const char *e = getenv("KISS_HIP_SMALL_SEG")) { // tuning hook
-        int v = atoi(e);
-        if (v >= 2 && v <= 4096) small_seg = (uint32_t)v;
-    }
+    // deviations recorded per member and round: 3 (the hooks build can sweep 1 .. 8)
+    const int pivot_slots = ctx->opts.pivot_slots >= 1 && ctx->opts.pivot_slots <= 8 ? ctx->opts.pivot_slots : 3;
+    const bool no_pair_keys = !ctx->opts.pair_keys;
+    const uint32_t small_seg = ctx->opts.small_seg >= 2 && ctx->opts.small_seg <= 4096 ? ctx->opts.small_seg : LMS_SMALL_SEG;
 
     // ------------------------------ round 0 ------------------------------------------------
     uint64_t count = m_far;
@@ -1257,7 +1250,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint32_t *Pc = rb.pos[res ^ 1]; // receives the survivors' positions
     uint64_t tot;
     bool have_tctx = false; // bslot is free until the big-segment path of the first round: the tied items' context words
-    const bool no_onepass = getenv("KISS_HIP_NO_FC0_ONEPASS") != nullptr; // A-B hook: count + scan + compact
+    const bool no_onepass = ctx->opts.no_fc0_onepass;
     const uint64_t tiles1 = div_up(count, FC1_TILE);
     // (the result of the five passes is in buffer 1 = the output list itself, so there are no positions to copy)
     const bool onepass = !no_onepass && ctx->fc_desc && tiles1 >= 8 && tiles1 + 1 <= ctx->fc_desc_cap &&
@@ -1391,7 +1384,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             const int kbits = slots * (dbits + 4) + 1;
             const int key_lo = 64 - 8 * ((kbits + 7) / 8);
             // room for the members' context words below the sorted bits (k = 256: 40 key bits, 24 bits free)
-            const bool with_ctx = key_lo >= 24 && getenv("KISS_HIP_NO_PIVOT_CTX") == nullptr; // (A-B hook)
+            const bool with_ctx = key_lo >= 24 && !ctx->opts.no_pivot_ctx;
             {
                 KTimer t(ctx, KISS_HIP_K_SEGRANK, nbig);
                 hipLaunchKernelGGL(k_pivot_lcp, dim3(bgrid), dim3(T), 0, ctx->stream, ctx->pk, ctx->bposA, ctx->bsegA, bss, nbig,
@@ -1399,7 +1392,8 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                 pivot_rounds_done++;
                 KCHECK(hipGetLastError());
             }
-            if (const char *dump = getenv("KISS_HIP_DUMP_PIVOT")) { // debugging aid: the inputs and keys of this pivot round
+#ifdef KISS_HIP_HOOKS
+            if (const char *dump = ctx->opts.dump_pivot[0] ? ctx->opts.dump_pivot : nullptr) { // debugging aid: the inputs and keys of this pivot round
                 std::vector<uint32_t> hp(nbig), hs(nbig), hss(nbigseg + 1);
                 std::vector<uint64_t> hk(nbig);
                 KCHECK(hipStreamSynchronize(ctx->stream));
@@ -1419,6 +1413,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                     fclose(f);
                 }
             }
+#endif
             RadixBufs pb;
             pb.key[0] = ctx->bkeyB;
             pb.key[1] = ctx->keyB; // free since the round-0 compaction (K1 is keyA)
@@ -1802,7 +1797,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
     ctx->stats.refine_form = 2;
     const uint64_t total = n + 1;
     const unsigned T = LS_THREADS;
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
+    const bool dbg = ctx->opts.debug;
     KTRY(kiss_need_ctx_words(ctx));
     uint32_t *isa = ctx->CTX; // the induction's context words are dead by now: (n + 2) u32
     uint64_t *d_total = (uint64_t *)(ctx->d_small + 2);
@@ -1834,7 +1829,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
                 fprintf(stderr, "[kiss_hip] refine: %llu of %llu suffix-array entries are tainted\n", hc, (unsigned long long)total);
             }
             // the context words are still in CTX (it becomes the inverse suffix array only after this kernel)
-            const bool no_taint = getenv("KISS_HIP_NO_TAINT") != nullptr; // A-B hook (read per call): compare every neighbour pair
+            const bool no_taint = ctx->opts.no_taint; // (hooks build: compare every neighbour pair)
             bool done = false;
             if (!no_taint && ctx->ctx_words_valid) {
                 // candidates first, compared densely afterwards; the list lives in posA (dead here).  More candidates than
@@ -1872,7 +1867,7 @@ int kiss_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *d_SA
         if (count == 0) break;
         ctx->ctx_words_valid = false; // CTX becomes the inverse suffix array from here on
         // the inverse suffix array is only needed when something is tied
-        if (getenv("KISS_HIP_ISA_DIRECT")) { // measurement hook: the plain random scatter
+        if (ctx->opts.isa_direct) { // (hooks build: the plain random scatter)
             KTimer t(ctx, KISS_HIP_K_ISA, total);
             hipLaunchKernelGGL(k_isa_init, dim3((unsigned)div_up(total, T)), dim3(T), 0, ctx->stream, d_SA, total, isa);
         } else if ((rc = kiss_isa_build(ctx, d_SA, total, isa)))
@@ -2195,9 +2190,9 @@ int kiss_lms_exact_refine(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint32_t *
     if (h0 < 32 || n < h0 || !scratch) return KINTERNAL();
     const uint64_t m = ctx->m;
     const unsigned T = LS_THREADS;
-    const bool dbg = getenv("KISS_HIP_DEBUG") != nullptr;
-    // experiment hook: bit i set = the host waits for the stream at sync point i of every round
-    const unsigned sync_points = getenv("KISS_HIP_LX_SYNC_POINTS") ? (unsigned)strtoul(getenv("KISS_HIP_LX_SYNC_POINTS"), nullptr, 0) : 0u;
+    const bool dbg = ctx->opts.debug;
+    // hooks build: bit i set = the host waits for the stream at sync point i of every round
+    const unsigned sync_points = ctx->opts.lx_sync_points;
     auto sync_point = [&](unsigned i) {
         if ((sync_points >> i) & 1u) (void)hipStreamSynchronize(ctx->stream);
     };

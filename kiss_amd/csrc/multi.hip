@@ -95,7 +95,7 @@ struct SharedDeviceLock {
     {
         bool shared = false;
         for (int q = 0; q < mc->G; q++) shared = shared || (q != r && mc->dev[q] == mc->dev[r]);
-        if (shared && !getenv("KISS_HIP_NO_SERIALIZE")) lk = std::unique_lock<std::mutex>(kiss_device_mutex(mc->dev[r]));
+        if (shared && !mc->ctx[r]->opts.no_serialize) lk = std::unique_lock<std::mutex>(kiss_device_mutex(mc->dev[r]));
     }
 };
 
@@ -191,6 +191,9 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     };
     const uint64_t lo = (n * (uint64_t)r) / (uint64_t)G, hi = (n * (uint64_t)(r + 1)) / (uint64_t)G;
     const uint64_t words = div_up(n, 32) + 4;
+    kiss_opts_refresh(ctx);
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev on this ctx: never this path's, api.hip)
+    ctx->h_depth = 0;
 
     // ---- packed text: device 0 packs, the others pull
     if (ok() && r == 0) {
@@ -344,7 +347,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
         // tie flags by comparison (the sort's own flags stayed on the devices that sorted), bin sizes of the rank array
         // counted from the gathered list (the ascending list is spread over the devices)
         bool lms_resolved = false;
-        if (!rc && sh->h0 && !getenv("KISS_HIP_NO_LMS_EXACT")) {
+        if (!rc && sh->h0 && !ctx->opts.no_lms_exact) {
             ctx->lms_pos_complete = false;
             ctx->hfar = nullptr;
             rc = kiss_lms_exact_refine(ctx, n, sh->h0, sh->d_SA, &lms_resolved);

@@ -14,9 +14,27 @@
 //    classification key for suffixes that round 0 of the sort made unique, a 15-base text gather for the rest.
 #include "kiss_internal.hpp"
 
+// ---- flight recorder of the near-end tie marks (hooks build only, KISS_HIP_TIE_TRACE=1) ----------------
+// What k_near_tie_runs computed and saw, what k_near_tie_mark read, when each ran, and what a later kernel finds in the
+// same places: compared on the host after the sort (kiss_tie_trace_report).
+#ifdef KISS_HIP_HOOKS
+#define KISS_TRACE(...) __VA_ARGS__
+#define KISS_TRACE_PARAM , uint32_t *dbg
+#define KISS_TRACE_ARG(ctx) , (ctx)->tie_dbg_on ? (ctx)->tie_dbg : (uint32_t *)nullptr
+#else
+#define KISS_TRACE(...)
+#define KISS_TRACE_PARAM
+#define KISS_TRACE_ARG(ctx)
+#endif
+
 namespace {
 
 constexpr int PL_THREADS = 256;
+#ifdef KISS_HIP_HOOKS
+// trace layout (32-bit words): header [0, 16), then per near-end suffix e < TT_MAX_E
+constexpr uint32_t TT_MAX_E = 1024, TT_RUNS = 16, TT_MARK = TT_RUNS + 8 * TT_MAX_E, TT_POST = TT_MARK + 4 * TT_MAX_E,
+                   TT_WORDS = TT_POST + 8 * TT_MAX_E;
+#endif
 
 // compare len bases at i and j (both ranges inside the text): <0, 0, >0
 __device__ int cmp_bases(const uint64_t *__restrict__ pk, uint64_t i, uint64_t j, uint64_t len)
@@ -287,9 +305,10 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
                                                              const uint32_t *__restrict__ far_sorted,
                                                              const uint32_t *__restrict__ near_pos,
                                                              const uint32_t *__restrict__ near_idx, uint32_t E,
-                                                             uint32_t *__restrict__ run_start)
+                                                             uint32_t *__restrict__ run_start KISS_TRACE_PARAM)
 {
     const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    KISS_TRACE(if (dbg && e == 0) { dbg[0] = E; dbg[1] = (uint32_t)k; dbg[8] = (uint32_t)wall_clock64(); })
     if (e >= E) return;
     const uint64_t pe = near_pos[e];
     const uint64_t hi = near_idx[e]; // far suffixes [0, hi) sort before e
@@ -318,6 +337,20 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
     }
     (void)bad;
     run_start[e] = (uint32_t)lo; // far suffixes [lo, hi) tie with e
+    KISS_TRACE(if (dbg && e < TT_MAX_E) {
+        uint32_t *r = dbg + TT_RUNS + 8 * e;
+        const uint32_t f1 = hi >= 1 ? far_sorted[hi - 1] : 0xFFFFFFFFu, f2 = hi >= 2 ? far_sorted[hi - 2] : 0xFFFFFFFFu,
+                       f3 = hi >= 3 ? far_sorted[hi - 3] : 0xFFFFFFFFu;
+        r[0] = (uint32_t)lo;
+        r[1] = (uint32_t)hi;
+        r[2] = f1;
+        r[3] = (hi >= 1 && shares_k(pk, n, k, f1, pe) ? 1u : 0u) | (hi >= 2 && shares_k(pk, n, k, f2, pe) ? 2u : 0u) |
+               (hi >= 3 && shares_k(pk, n, k, f3, pe) ? 4u : 0u);
+        r[4] = f2;
+        r[5] = f3;
+        r[6] = (uint32_t)pe;
+        r[7] = (uint32_t)wall_clock64(); // (end of this thread; the host takes the latest)
+    })
 }
 
 // far_ctx[j] |= taint for j in [run_start[e], near_idx[e]): NT_BLOCKS workgroups per near suffix, grid-stride over its run
@@ -328,12 +361,23 @@ constexpr uint32_t NT_MAX_GRID = 1u << 20;
 __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__restrict__ run_start,
                                                              const uint32_t *__restrict__ near_idx,
                                                              uint32_t *__restrict__ far_ctx, uint32_t E,
-                                                             uint8_t *__restrict__ hfar) // optional (ctx->hfar): the far suffixes
-                                                             // of a run share k bases with each other too -- one group
+                                                             uint8_t *__restrict__ hfar // optional (ctx->hfar): the far suffixes
+                                                             KISS_TRACE_PARAM) // of a run share k bases with each other too -- one group
 {
+    KISS_TRACE(if (dbg && threadIdx.x == 0 && blockIdx.x == 0) {
+        dbg[4] = E;
+        dbg[5] = hfar ? 1u : 0u;
+        dbg[6] = (uint32_t)wall_clock64(); // start of the first workgroup
+    })
     for (uint64_t b = blockIdx.x; b < (uint64_t)NT_BLOCKS * E; b += gridDim.x) {
         const uint32_t e = (uint32_t)(b / NT_BLOCKS), sub = (uint32_t)(b % NT_BLOCKS);
         const uint64_t lo = run_start[e], hi = near_idx[e];
+        KISS_TRACE(if (dbg && threadIdx.x == 0 && e < TT_MAX_E && sub == 0) {
+            uint32_t *q = dbg + TT_MARK + 4 * e;
+            q[0] = (uint32_t)lo;
+            q[1] = (uint32_t)hi;
+            q[2] = (uint32_t)wall_clock64();
+        })
         for (uint64_t j = lo + (uint64_t)sub * PL_THREADS + threadIdx.x; j < hi; j += (uint64_t)NT_BLOCKS * PL_THREADS) {
             far_ctx[j] |= KISS_CTX_TAINT; // (a word of 0 = "gather me" becomes 0x80000000: still gathered, see k_merge_far)
             if (hfar && j > lo) hfar[j] = 0;
@@ -382,9 +426,26 @@ namespace {
 // near-end suffixes by ascending merged index (E is small here: all pairs)
 __global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__restrict__ near_pos,
                                                           const uint32_t *__restrict__ near_fin, uint32_t E,
-                                                          uint32_t *__restrict__ tab_fin, uint32_t *__restrict__ tab_pos)
+                                                          uint32_t *__restrict__ tab_fin, uint32_t *tab_pos
+                                                          KISS_TRACE(, uint32_t *dbg, const uint32_t *tt_far, const uint32_t *tt_ctx,
+                                                                     const uint8_t *tt_hfar, const uint32_t *tt_idx))
 {
     const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    KISS_TRACE(
+        if (dbg && e == 0) dbg[3] = (uint32_t)wall_clock64();
+        if (dbg && e < E && e < TT_MAX_E) { // the same places again, as the kernel after the marks finds them (tab_pos[e] = run_start[e] still)
+            const uint64_t hi = tt_idx[e];
+            uint32_t *q = dbg + TT_POST + 8 * e;
+            q[0] = (uint32_t)hi;
+            q[1] = hi >= 1 ? tt_far[hi - 1] : 0xFFFFFFFFu;
+            q[2] = hi >= 2 ? tt_far[hi - 2] : 0xFFFFFFFFu;
+            q[3] = hi >= 3 ? tt_far[hi - 3] : 0xFFFFFFFFu;
+            q[4] = tt_hfar ? ((hi >= 1 ? tt_hfar[hi - 1] : 9u) | (hi >= 2 ? tt_hfar[hi - 2] : 9u) << 8 | (hi >= 3 ? tt_hfar[hi - 3] : 9u) << 16) : 0xFFFFFFFFu;
+            q[5] = (hi >= 1 ? tt_ctx[hi - 1] >> 31 : 9u) | (hi >= 2 ? tt_ctx[hi - 2] >> 31 : 9u) << 8 | (hi >= 3 ? tt_ctx[hi - 3] >> 31 : 9u) << 16;
+            q[6] = tab_pos[e];
+        }
+        if (dbg) __syncthreads(); // (one workgroup, E <= 256: every thread has read its tab_pos[e] before any thread overwrites the array)
+    )
     if (e >= E) return;
     const uint32_t fe = near_fin[e];
     uint32_t r = 0;
@@ -392,6 +453,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__res
     tab_fin[r] = fe;
     tab_pos[r] = near_pos[e];
 }
+
 
 } // namespace
 
@@ -410,9 +472,8 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     KTRY(near_reserve(ctx, E64 ? E64 : 1));
     const uint32_t E = (uint32_t)E64;
     // pairwise ranking is the cheapest form for the handful of near-end suffixes of k = 32 / 256 (E ~ 0.3 D); beyond
-    // this size the merge-sort form takes over.  KISS_HIP_NEAR_MERGE_MIN (test hook) moves the switch.
-    uint32_t merge_min = 4096;
-    if (const char *ev = getenv("KISS_HIP_NEAR_MERGE_MIN")) merge_min = (uint32_t)strtoul(ev, nullptr, 10);
+    // this size the merge-sort form takes over (the hooks build can move the switch).
+    const uint32_t merge_min = ctx->opts.near_merge_min;
     {
         KTimer t(ctx, KISS_HIP_K_PLACE, m);
         const unsigned egrid = (unsigned)div_up(E ? E : 1, PL_THREADS);
@@ -435,9 +496,9 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2);
+                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE(, (uint32_t *)nullptr));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr);
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE(, (uint32_t *)nullptr));
             }
             ctx->near_form = 2;
             ctx->near_sorted = near_sorted;
@@ -445,19 +506,31 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             ctx->rm_pos = near_sorted;
         } else if (E > 0) {
             const uint32_t *near_pos = ctx->lms_pos + m_far; // ascending list: the near-end suffixes are its tail
+#ifdef KISS_HIP_HOOKS
+            ctx->tie_dbg_on = false;
+            if (ctx->opts.tie_trace && m_far && (uint64_t)k < n) {
+                if (!ctx->tie_dbg && hipMalloc((void **)&ctx->tie_dbg, TT_WORDS * sizeof(uint32_t)) != hipSuccess) ctx->tie_dbg = nullptr;
+                if (ctx->tie_dbg) { // (every word read by the report is written by this sort's kernels: nothing to clear)
+                    ctx->tie_dbg_on = true;
+                    ctx->tie_dbg_E = E;
+                    ctx->tie_dbg_k = k;
+                }
+            }
+#endif
             hipLaunchKernelGGL(k_near_rank, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
                                ctx->lms_sorted_far, m_far, near_pos, E, ctx->near_idx);
             hipLaunchKernelGGL(k_near_order, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k, near_pos,
                                ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2);
+                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_ARG(ctx));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr);
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_ARG(ctx));
             }
             // (stream order: k_near_tie_mark has read near_tmp2 before the table overwrites it)
             hipLaunchKernelGGL(k_near_table, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, near_pos, ctx->near_fin, E, ctx->near_tmp,
-                               ctx->near_tmp2);
+                               ctx->near_tmp2 KISS_TRACE_ARG(ctx) KISS_TRACE(, ctx->lms_sorted_far, ctx->lms_ctx_far,
+                                              (k == ctx->h_depth) ? ctx->hfar : (const uint8_t *)nullptr, ctx->near_idx));
             ctx->near_form = 1;
             ctx->rm_fin = ctx->near_tmp;
             ctx->rm_pos = ctx->near_tmp2;
@@ -465,7 +538,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         ctx->rm_E = E;
         KCHECK(hipGetLastError());
     }
-    const bool merge_now = getenv("KISS_HIP_MERGE_LMS") != nullptr; // A-B hook: the merged copy of round 1
+    const bool merge_now = ctx->opts.merge_lms; // (hooks build: the merged copy of round 1)
     if (merge_now) KTRY(kiss_merge_lms(ctx));
     return KISS_HIP_OK;
 }
@@ -515,3 +588,57 @@ int kiss_merge_lms(kiss_hip_ctx *ctx)
     ctx->lms_merged = true;
     return KISS_HIP_OK;
 }
+
+#ifdef KISS_HIP_HOOKS
+// after the sort has finished (stream synchronised): one line per traced sort with KISS_HIP_TIE_TRACE=2, and a dump of
+// everything recorded when what the kernels saw does not fit together
+void kiss_tie_trace_report(kiss_hip_ctx *ctx)
+{
+    if (!ctx->tie_dbg_on || !ctx->tie_dbg) return;
+    ctx->tie_dbg_on = false;
+    std::vector<uint32_t> h(TT_WORDS);
+    // (on the context's own stream: a plain hipMemcpy would wait for every other stream of the device, the other thread's too)
+    if (hipMemcpyAsync(h.data(), ctx->tie_dbg, TT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return;
+    const uint32_t E = ctx->tie_dbg_E < TT_MAX_E ? ctx->tie_dbg_E : TT_MAX_E;
+    const uint64_t n = ctx->n, k = ctx->tie_dbg_k;
+    unsigned bad_read = 0, bad_list = 0, bad_mark = 0, can_tie = 0, empty_runs = 0;
+    uint32_t runs_end = 0;
+    bool have_end = false;
+    int first = -1;
+    for (uint32_t e = 0; e < E; e++) {
+        const uint32_t *r = &h[TT_RUNS + 8 * e], *q = &h[TT_MARK + 4 * e], *p = &h[TT_POST + 8 * e];
+        if (n - r[6] < k) continue; // fewer than k bases left: ties with nothing
+        if (first < 0) first = (int)e;
+        can_tie++;
+        if (r[1] - r[0] < 2) empty_runs++;
+        if (q[0] != r[0] || q[1] != r[1] || p[6] != r[0]) bad_read++;
+        if ((int32_t)(r[7] - runs_end) > 0 || !have_end) { runs_end = r[7]; have_end = true; }
+        if (p[1] != r[2] || p[2] != r[4] || p[3] != r[5] || p[0] != r[1]) bad_list++;
+        if (r[1] - r[0] >= 2 && ((p[5] & 0xFF) != 1 || (p[4] != 0xFFFFFFFFu && (p[4] & 0xFF) != 0))) bad_mark++;
+    }
+    // clock order: last thread of the runs kernel < first workgroup of the mark kernel < table kernel
+    const bool order_bad = (can_tie && ((int32_t)(h[6] - runs_end) < 0 || (int32_t)(h[3] - h[6]) < 0));
+    const bool hdr_bad = h[0] != ctx->tie_dbg_E || h[4] != ctx->tie_dbg_E || h[1] != (uint32_t)k;
+    const bool anomaly = bad_read || bad_list || bad_mark || order_bad || hdr_bad;
+    if (ctx->opts.tie_trace >= 2 || anomaly) {
+        fprintf(stderr, "[kiss_hip] tie_trace%s ctx %p n %llu k %llu E %u (kernels saw E %u / %u, k %u, hfar %u): %u near-end suffixes can tie, "
+                        "%u with a run < 2; mark kernel read something else for %u, far list changed for %u, marks missing for %u; "
+                        "ticks since the runs kernel started: runs end %u, mark start %u, table start %u\n",
+                anomaly ? " ANOMALY" : "", (void *)ctx, (unsigned long long)n, (unsigned long long)k, ctx->tie_dbg_E, h[0], h[4], h[1], h[5],
+                can_tie, empty_runs, bad_read, bad_list, bad_mark, runs_end - h[8], h[6] - h[8], h[3] - h[8]);
+        if (first >= 0) {
+            int shown = 0;
+            for (uint32_t e = (uint32_t)first; e < E && shown < (anomaly ? 6 : 1); e++) {
+                const uint32_t *r = &h[TT_RUNS + 8 * e], *q = &h[TT_MARK + 4 * e], *p = &h[TT_POST + 8 * e];
+                if (n - r[6] < k) continue;
+                shown++;
+                fprintf(stderr, "[kiss_hip]   e %u pos %u: runs kernel lo %u hi %u far[hi-1..hi-3] %u %u %u shares %u | mark kernel read lo %u hi %u "
+                                "| afterwards hi %u far %u %u %u hfar %06x taint %06x run start %u\n",
+                        e, r[6], r[0], r[1], r[2], r[4], r[5], r[3], q[0], q[1], p[0], p[1], p[2], p[3], p[4], p[5], p[6]);
+            }
+        }
+    }
+}
+#endif

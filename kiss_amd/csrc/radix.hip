@@ -652,7 +652,7 @@ int kiss_radix_sort(kiss_hip_ctx *ctx, RadixBufs &b, uint64_t count, int key_lo_
         const int shift0 = key_lo_bit & ~7;
         const int n_key = (64 - shift0) / 8, n_seg = (seg_bits + 7) / 8;
         const uint64_t tiles = div_up(count, RX_TILE);
-        const bool no_one = getenv("KISS_HIP_NO_ONESWEEP") != nullptr; // measurement hook (read per call)
+        const bool no_one = ctx->opts.no_onesweep; // (hooks build)
         const bool one = !no_one && ctx->rx_desc && tiles >= 2 && tiles <= ctx->rx_tiles_cap && n_key + n_seg <= RX_MAX_PASSES;
         // digit counts that came with the keys (classify.hip, round 0 only)
         const bool counted = one && ctx->rx_ghist_count == count && !has_seg && shift0 == KISS_R0_SHIFT && b.first_pos;

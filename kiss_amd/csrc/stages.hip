@@ -122,7 +122,10 @@ int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, u
 {
     if (!ctx || !d_S || !counts13 || n == 0 || n > ctx->max_n || lo > hi || hi > n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     std::memset(&ctx->stats, 0, sizeof ctx->stats);
     ctx->stats.n = n;
@@ -186,7 +189,10 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
 {
     if (!ctx || !d_hist || bits < 1 || bits > 24 || (count && !d_keys)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     KTRY(kiss_key_hist(ctx, d_keys, count, bits, d_hist));
     KCHECK(hipStreamSynchronize(ctx->stream));
@@ -201,7 +207,10 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
     if (count && (!d_keys || !d_pos || !d_keys_out || !d_pos_out)) return KISS_HIP_E_INVALID;
     if (count > ctx->m_cap) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     if (count == 0) return KISS_HIP_OK;
     if (groups == 1) { // nothing to move (callers that hold views of the ctx's own buffers skip this call altogether)
@@ -220,7 +229,10 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     if (!ctx || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID; // stage_classify packed the text of this ctx
     if (count && (!d_keys || !d_pos || !d_sorted_out)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     if (count > ctx->m_cap) KTRY(kiss_lms_reserve(ctx, count + count / 64 + 1024));
     // the ctx's own buffers (kiss_hip_stage_view) are sorted where they are: no copy in, no copy out
@@ -258,7 +270,10 @@ static int stage_induce_impl(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint32_t
     if (!ctx || !counts12 || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID;
     if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     const uint64_t m = m_far + near_count;
     const bool in_place = d_far_sorted == ctx->lms_sorted_far; // views of the ctx's own buffers: nothing to copy
@@ -283,7 +298,7 @@ static int stage_induce_impl(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint32_t
     const uint64_t depth = depth_of(n, k);
     KTRY(kiss_place_lms(ctx, n, k, depth));
     bool resolved = false;
-    if (exact_h0 && !getenv("KISS_HIP_NO_LMS_EXACT")) {
+    if (exact_h0 && !ctx->opts.no_lms_exact) {
         // the gathered list is h0-ordered: exact order of the LMS suffixes by rank doubling before the induction, as in the
         // one-device path (api.hip: sort_dev); tie flags by comparison, bin sizes of the rank array counted from the list
         ctx->lms_pos_complete = false;
@@ -324,7 +339,10 @@ int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint
     if (!ctx || !d_SA || n == 0 || n != ctx->n) return KISS_HIP_E_INVALID; // stage_classify packed the text of this ctx
     if (h0 < 32 || n < 4ull * h0 + 1024) return KISS_HIP_E_UNSUPPORTED;
     KCHECK(hipSetDevice(ctx->device));
+    kiss_opts_refresh(ctx);
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
+    ctx->h_depth = 0;
     KTRY(kiss_workspace_ready(ctx));
     KTRY(kiss_exact_refine(ctx, n, h0, d_SA));
     KCHECK(hipStreamSynchronize(ctx->stream));

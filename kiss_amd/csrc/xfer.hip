@@ -20,15 +20,14 @@
 namespace {
 
 constexpr int XF_MAX_THREADS = 16;
-// copy threads for pageable memory (each with two bounce buffers and a stream): KISS_HIP_XFER_THREADS, default 8
-// (read per call like every other hook; the pool below holds buffers for XF_MAX_THREADS and creates them on demand)
-static int xf_threads()
+// copy threads for pageable memory (each with two bounce buffers and a stream): 8, or what KISS_HIP_XFER_THREADS said when
+// the context was created (KissOpts; the pool below holds buffers for XF_MAX_THREADS and creates them on demand)
+static int xf_threads(const kiss_hip_ctx *ctx)
 {
-    const char *e = getenv("KISS_HIP_XFER_THREADS");
-    const int v = e ? atoi(e) : 8;
+    const int v = ctx->opts.xfer_threads ? ctx->opts.xfer_threads : 8;
     return v < 1 ? 1 : (v > XF_MAX_THREADS ? XF_MAX_THREADS : v);
 }
-#define XF_THREADS xf_threads()
+#define XF_THREADS xf_threads(ctx)
 constexpr size_t XF_CHUNK = 16ull << 20;
 
 bool host_is_pinned(const void *p)
@@ -198,20 +197,16 @@ static bool looks_untouched(uint64_t lo, uint64_t hi, uint64_t page)
     return asked && missing * 2 > asked;
 }
 
-void *kiss_prefault_start(void *p, uint64_t bytes)
+void *kiss_prefault_start(kiss_hip_ctx *ctx, void *p, uint64_t bytes)
 {
-    const bool off = getenv("KISS_HIP_NO_PREFAULT") != nullptr; // A-B hook (read per call)
-    if (off || bytes < (64ull << 20)) return nullptr;
+    if (ctx->opts.no_prefault || bytes < (64ull << 20)) return nullptr;
     const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
     const uint64_t lo = ((uint64_t)(uintptr_t)p + page - 1) / page * page, hi = ((uint64_t)(uintptr_t)p + bytes) / page * page;
     if (hi <= lo || !looks_untouched(lo, hi, page)) return nullptr;
     kiss_prefault *h = new (std::nothrow) kiss_prefault;
     if (!h) return nullptr;
     int T = 4; // measured 4 / 8 / 14: more helpers take more from the thread that drives the sort than they give
-    if (const char *e = getenv("KISS_HIP_PREFAULT_THREADS")) { // tuning hook
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) T = v;
-    }
+    if (ctx->opts.prefault_threads >= 1 && ctx->opts.prefault_threads <= 64) T = ctx->opts.prefault_threads;
     const uint64_t pages = (hi - lo) / page, per = (pages + (uint64_t)T - 1) / (uint64_t)T;
     for (int t = 0; t < T; t++) {
         const uint64_t a = lo + (uint64_t)t * per * page, b = a + per * page < hi ? a + per * page : hi;

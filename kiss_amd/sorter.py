@@ -17,12 +17,16 @@ from . import _lib
 K_UNBOUNDED = 0xFFFFFFFF  # the CLI's `-k -1` (size_t max truncated to uint32_t, suffix_sort.hpp:35-37)
 
 
+_CTX_LIB = {}  # context handle -> the library that made it (default or hooks build)
+
+
 def _check(status, where, ctx=None):
     if status != _lib.KISS_HIP_OK:
         detail = ""
         if ctx is not None:
             msg = ctypes.c_char_p()
-            code = _lib.load().kiss_hip_last_hip_error(ctx, ctypes.byref(msg))
+            lib = _CTX_LIB.get(getattr(ctx, "value", ctx)) or _lib.load()
+            code = lib.kiss_hip_last_hip_error(ctx, ctypes.byref(msg))
             if code:
                 detail = "hip error %d: %s" % (code, (msg.value or b"").decode())
         raise _lib.KissHipError(status, where, detail)
@@ -31,13 +35,16 @@ def _check(status, where, ctx=None):
 class Context:
     """Device workspace for texts up to max_n bases on one GPU (kiss_hip_ctx)."""
 
-    def __init__(self, max_n, device=0, profiling=False, lms_capacity=0):
+    def __init__(self, max_n, device=0, profiling=False, lms_capacity=0, hooks=None):
         """lms_capacity (optional): capacity of the per-LMS-suffix work arrays instead of 0.32 max_n -- a rank > 0 of a
-        sharded sort holds about 1/G of the LMS suffixes (kiss_hip_ctx_create_sized; the arrays regrow on demand)"""
-        self._lib = _lib.load()
+        sharded sort holds about 1/G of the LMS suffixes (kiss_hip_ctx_create_sized; the arrays regrow on demand).
+        hooks=True: a context of the hooks build (libkiss_hip_hooks.so), the only one whose behaviour KISS_HIP_*
+        environment switches change (tests of the rare paths)."""
+        self._lib = _lib.load(hooks)
         self._ctx = ctypes.c_void_p()
         _check(self._lib.kiss_hip_ctx_create_sized(ctypes.byref(self._ctx), int(device), int(max_n), int(lms_capacity)),
                "kiss_hip_ctx_create_sized")
+        _CTX_LIB[self._ctx.value] = self._lib
         self._owned = True
         self.max_n = int(max_n)
         self.device = int(device)
@@ -56,6 +63,7 @@ class Context:
 
     def close(self):
         if self._ctx and self._owned:
+            _CTX_LIB.pop(self._ctx.value, None)
             self._lib.kiss_hip_ctx_destroy(self._ctx)
         self._ctx = ctypes.c_void_p()
 
@@ -263,13 +271,13 @@ class KISS1Sorter:
         return SA
 
 
-def suffix_array_bytes(data, device=0):
+def suffix_array_bytes(data, device=0, hooks=None):
     """Exact suffix array (uint32, n + 1 entries, SA[0] = n) of a text over the byte alphabet: the general-alphabet
     entry of the reference facade, KISS1Sorter::get_suffix_array (kiss1_sorter.hpp:28-45 -> kiss1_core.hpp:270-311)."""
     S = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data,
                              dtype=np.uint8)
     SA = np.empty(S.size + 1, dtype=np.uint32)
-    lib = _lib.load()
+    lib = _lib.load(hooks)  # (hooks=True: the hooks build, for the tests that switch paths through the environment)
     _check(lib.kiss_hip_suffix_sort_u8(S.ctypes.data if S.size else None, S.size, SA.ctypes.data, int(device)),
            "kiss_hip_suffix_sort_u8")
     return SA

@@ -78,3 +78,27 @@ def test_cpp_host_facade_compiles_and_links(tmp_path):
            str(exe), "-L" + os.path.join(ROOT, "kiss_amd"), "-lkiss_hip", "-Wl,-rpath," + os.path.join(ROOT, "kiss_amd")]
     subprocess.check_call(cmd)
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_shipped_library_has_no_environment_hooks():
+    # the default libkiss_hip.so looks at the environment once per context and only for three host-side
+    # knobs; every A-B switch, tuning value, fault injection and trace exists in libkiss_hip_hooks.so (-DKISS_HIP_HOOKS) only
+    import subprocess
+    default, hooks = kiss_amd.load(False), kiss_amd.load(True)
+    assert default.kiss_hip_has_hooks() == 0 and hooks.kiss_hip_has_hooks() == 1
+    for s in _lib.EXPORTED_SYMBOLS:
+        assert hasattr(hooks, s), "hooks build misses export " + s
+    names = set(re.findall(rb"KISS_HIP_[A-Z0-9_]+", open(_lib.LIB_PATH, "rb").read()))
+    assert names == {b"KISS_HIP_DEBUG", b"KISS_HIP_XFER_THREADS", b"KISS_HIP_PREFAULT_THREADS"}, sorted(names)
+    assert b"KISS_HIP_NO_SERIALIZE" in open(_lib.HOOKS_LIB_PATH, "rb").read()
+    # and in the sources: getenv only in api.hip's two option readers (one of them compiled into the hooks build only)
+    csrc = os.path.join(ROOT, "kiss_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        if fn != "api.hip":
+            assert "getenv" not in text, fn
+            continue
+        body = re.sub(r"#ifdef KISS_HIP_HOOKS.*?#endif", "", text, flags=re.S)
+        assert body.count("getenv(") == 3, body.count("getenv(")  # KISS_HIP_DEBUG / _XFER_THREADS / _PREFAULT_THREADS

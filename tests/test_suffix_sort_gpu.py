@@ -16,6 +16,16 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def hctx():
+    # a context of the hooks build (libkiss_hip_hooks.so): the only one whose behaviour KISS_HIP_* environment switches
+    # change -- the tests that force the rare paths and compare the A-B forms use it; everything else runs on the shipped library
+    import kiss_amd
+    c = kiss_amd.Context(max_n=6_000_000, device=0, hooks=True)
+    yield c
+    c.close()
+
+
 def check_parity(ctx, oracle, S, k, stages=True):
     S = np.ascontiguousarray(S, dtype=np.uint8)
     n = S.size
@@ -165,15 +175,15 @@ def test_prefix_doubling_exact(ctx, oracle, shape):
         assert st["doubling_rounds"] <= 14  # log2(n / 256) + slack, not n / 32
 
 
-def test_prefix_doubling_small_and_depths(ctx, oracle, monkeypatch):
+def test_prefix_doubling_small_and_depths(hctx, oracle, monkeypatch):
     import kiss_amd
     for n in [0, 1, 2, 31, 300, 1024, 2047, 2048, 2049, 5000]:
         S = gen.periodic(n, 3, 1, mutations=2) if n > 10 else gen.iid(n, n)
-        _exact_by_doubling(ctx, oracle, S)
+        _exact_by_doubling(hctx, oracle, S)
     S = gen.periodic(60_000, 37, 2, mutations=3)
     for h0 in ("32", "33", "64", "124", "125", "1000"):
         monkeypatch.setenv("KISS_HIP_DOUBLING_H0", h0)
-        st = _exact_by_doubling(ctx, oracle, S)
+        st = _exact_by_doubling(hctx, oracle, S)
         assert st["refine_depth"] == int(h0)
 
 
@@ -187,7 +197,7 @@ def test_prefix_doubling_binned_inverse(oracle, monkeypatch):
     S = gen.genome_like(n, 21)
     S[1000:9000] = 2                      # sorted stretches of SA (one-bin waves in the partition)
     S[2_000_000:2_300_000] = S[9_000_000:9_300_000]
-    c = kiss_amd.Context(max_n=n, device=0)
+    c = kiss_amd.Context(max_n=n, device=0, hooks=True)
     try:
         st = _exact_by_doubling(c, oracle, S)
         assert st["refine_items"] > 300_000
@@ -246,7 +256,7 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
     import kiss_amd
     from kiss_amd import _lib
     n = 200_000   # default reservation: 0.32 n LMS suffixes (545 kB of keys); ACAC.. has n/2 (821 kB)
-    c = kiss_amd.Context(max_n=n, device=0)
+    c = kiss_amd.Context(max_n=n, device=0, hooks=True)
     try:
         dna = gen.iid(n, 77)
         acac = np.tile(np.array([0, 1], np.uint8), n // 2)              # n/2 LMS suffixes, all of them tied
@@ -257,14 +267,14 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
                 # exact order through the LMS-level doubling needs no array beyond what the k = 256 sort of this text has
                 # grown already; the suffix-array form (all n suffixes tied) does: that is the growth that fails here
                 monkeypatch.setenv("KISS_HIP_NO_LMS_EXACT", "1")
-            assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 700000) == 0
+            assert _lib.load(True).kiss_hip_debug_fail_alloc_over(c._ctx, 700000) == 0
             with pytest.raises(kiss_amd.KissHipError) as e:
                 c.suffix_sort(acac, k)
             assert e.value.status == _lib.KISS_HIP_E_NOMEM
             with pytest.raises(kiss_amd.KissHipError) as e:             # still failing while memory is short, still cleanly
                 c.suffix_sort(acac, k)
             assert e.value.status == _lib.KISS_HIP_E_NOMEM
-            assert _lib.load().kiss_hip_debug_fail_alloc_over(c._ctx, 0) == 0
+            assert _lib.load(True).kiss_hip_debug_fail_alloc_over(c._ctx, 0) == 0
             assert np.array_equal(c.suffix_sort(dna, 256), want_dna)
             assert np.array_equal(c.suffix_sort(acac, k), oracle.suffix_sort(acac, k))
             monkeypatch.delenv("KISS_HIP_NO_LMS_EXACT", raising=False)
@@ -274,20 +284,20 @@ def test_context_recovers_after_running_out_of_memory(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("hook", ["KISS_HIP_NO_FC0_ONEPASS", "KISS_HIP_MERGE_LMS"])
-def test_round2_shortcuts_equal_the_forms_they_replace(ctx, oracle, monkeypatch, hook):
+def test_round2_shortcuts_equal_the_forms_they_replace(hctx, oracle, monkeypatch, hook):
     # KISS_HIP_NO_FC0_ONEPASS: round 0 flags + compacts with count / scan / compact instead of the one-pass look-back;
     # KISS_HIP_MERGE_LMS: the induction reads a merged copy of the LMS list instead of far list + near-end table.
     # Both forms must give the oracle's SA; with the tied-segment arrays too small for the first attempt as well
     # (the one-pass form learns the survivor count only afterwards and runs again).
     S = gen.genome_like(3_000_000, 31)
     want = oracle.suffix_sort(S, 256)
-    assert np.array_equal(ctx.suffix_sort(S, 256), want)
+    assert np.array_equal(hctx.suffix_sort(S, 256), want)
     monkeypatch.setenv(hook, "1")
-    assert np.array_equal(ctx.suffix_sort(S, 256), want)
+    assert np.array_equal(hctx.suffix_sort(S, 256), want)
     monkeypatch.delenv(hook)
     import kiss_amd
     rep = np.tile(gen.iid(3000, 5), 700)          # every LMS suffix tied after round 0: more than the default t_cap
-    c = kiss_amd.Context(max_n=rep.size, device=0)
+    c = kiss_amd.Context(max_n=rep.size, device=0, hooks=True)
     try:
         assert np.array_equal(c.suffix_sort(rep, 256), oracle.suffix_sort(rep, 256))
     finally:
@@ -368,9 +378,9 @@ def test_randomised_small_texts(ctx, oracle, block):
 
 
 def test_fallback_paths_in_a_fresh_process():
-    # two switches are read once per process / per workspace: KISS_HIP_NO_ONESWEEP (radix passes with per-tile
-    # histograms instead of look-back) and KISS_HIP_TCAP0 (tiny tied-segment arrays, so every growth path runs).
-    # One child process sorts a handful of texts with both set and compares with the oracle.
+    # two switches of the hooks build: KISS_HIP_NO_ONESWEEP (radix passes with per-tile histograms instead of
+    # look-back) and KISS_HIP_TCAP0 (tiny tied-segment arrays, so every growth path runs).
+    # One child process (KISS_AMD_LIB=hooks) sorts a handful of texts with both set and compares with the oracle.
     import os
     import subprocess
     import sys
@@ -387,7 +397,7 @@ for S in texts:
         assert np.array_equal(ctx.suffix_sort(S, k, algo=algo), orc.suffix_sort(S, k)), (S[:8], k, algo)
 print("variants ok")
 """
-    env = dict(os.environ, KISS_HIP_NO_ONESWEEP="1", KISS_HIP_TCAP0="1500", PYTHONPATH=root)
+    env = dict(os.environ, KISS_AMD_LIB="hooks", KISS_HIP_NO_ONESWEEP="1", KISS_HIP_TCAP0="1500", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variants ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -434,7 +444,7 @@ def test_bounded_k_with_many_near_end_suffixes(oracle, k):
         assert sa[0] == S.size
 
 
-def test_near_end_merge_form_equals_pairwise_form(ctx, oracle, monkeypatch):
+def test_near_end_merge_form_equals_pairwise_form(hctx, oracle, monkeypatch):
     # the same inputs through both near-end forms (the switch is read per call)
     rng = np.random.default_rng(77)
     base = rng.integers(0, 4, 30_000, dtype=np.uint8)
@@ -444,9 +454,9 @@ def test_near_end_merge_form_equals_pairwise_form(ctx, oracle, monkeypatch):
     for S in cases:
         for k in (32, 256, 1000):
             monkeypatch.setenv("KISS_HIP_NEAR_MERGE_MIN", "1")
-            a = check_parity(ctx, oracle, S, k)
+            a = check_parity(hctx, oracle, S, k)
             monkeypatch.setenv("KISS_HIP_NEAR_MERGE_MIN", "1000000000")
-            b = check_parity(ctx, oracle, S, k)
+            b = check_parity(hctx, oracle, S, k)
             assert np.array_equal(a, b)
     monkeypatch.delenv("KISS_HIP_NEAR_MERGE_MIN")
 
@@ -471,7 +481,7 @@ def test_pivot_rounds_equal_32_base_rounds(oracle, monkeypatch, k):
         S[c * 800:c * 800 + 600] = cp
     texts.append(S)
     texts.append(gen.periodic(600_000, 7, 3, mutations=60_000))
-    with kiss_amd.Context(max_n=2_400_000, device=0) as c:
+    with kiss_amd.Context(max_n=2_400_000, device=0, hooks=True) as c:
         for S in texts:
             want = oracle.suffix_sort(S, k)
             monkeypatch.delenv("KISS_HIP_NO_PIVOT_ROUNDS", raising=False)
@@ -520,7 +530,7 @@ def test_host_entry_into_a_destination_that_was_never_touched(monkeypatch):
     # helpers switched off
     import kiss_amd
     S = gen.iid(20_000_000, 77)
-    with kiss_amd.Context(max_n=S.size, device=0) as c:
+    with kiss_amd.Context(max_n=S.size, device=0, hooks=True) as c:
         warm = np.zeros(S.size + 1, dtype=np.uint32)
         c.suffix_sort_host(S, warm, k=256)
         assert warm[0] == S.size
@@ -571,7 +581,7 @@ def test_exact_order_lms_rank_array_two_level_one_bins(oracle, monkeypatch):
     S = gen.genome_like(n, 23)
     S[3_000_000:3_400_000] = S[30_000_000:30_400_000]   # ties that reach across the two bins
     S[n - 200_000:n - 100_000] = S[1_000_000:1_100_000]
-    with kiss_amd.Context(max_n=n, device=0) as c:
+    with kiss_amd.Context(max_n=n, device=0, hooks=True) as c:
         sa = c.suffix_sort(S, 0xFFFFFFFF, algo=1)
         st = c.stats()
         assert st["refine_form"] == 1 and st["refine_items"] > 100_000
@@ -622,7 +632,7 @@ def test_exact_order_lms_level_doubling(oracle, monkeypatch, shape):
     import kiss_amd
     S = _lms_exact_shapes(shape)
     want = oracle.suffix_sort(S, 0xFFFFFFFF)
-    with kiss_amd.Context(max_n=S.size, device=0) as c:
+    with kiss_amd.Context(max_n=S.size, device=0, hooks=True) as c:
         for direct_max in (None, "1000"):   # rank array by plain scatter / by the two-level partition (isa.hip)
             if direct_max:
                 monkeypatch.setenv("KISS_HIP_ISA_DIRECT_MAX", direct_max)
@@ -677,7 +687,7 @@ def test_exact_order_taint_shortcut_equals_comparing_every_pair(oracle, monkeypa
             monkeypatch.setenv("KISS_HIP_NO_TAINT", "1")
         else:
             monkeypatch.delenv("KISS_HIP_NO_TAINT", raising=False)
-        with kiss_amd.Context(max_n=n, device=0) as c:
+        with kiss_amd.Context(max_n=n, device=0, hooks=True) as c:
             assert np.array_equal(c.suffix_sort(S, 0xFFFFFFFF, algo=1), want)
             # sharded form: k = 256 through the stages, then stage_refine_exact
             dev = torch.device("cuda", 0)

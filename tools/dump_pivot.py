@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("KISS_AMD_LIB", "hooks")  # KISS_HIP_* switches exist in the hooks build only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import kiss_amd

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Exact order through the LMS-level doubling (kiss_lms_exact_refine) against the oracle and against the suffix-array form
 (KISS_HIP_NO_LMS_EXACT=1), shape by shape, with the library's debug trace.  Runs on the GPU box."""
-import os, sys, time
+import os, sys
+os.environ.setdefault("KISS_AMD_LIB", "hooks")  # KISS_HIP_* switches exist in the hooks build only
+import time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import kiss_amd
