@@ -245,7 +245,15 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
     S = gen_text_device(n, 1, device)
     S_host = S.cpu().numpy()
     del S
-    f = fm.FMIndex(device=device.index or 0).build(S_host)
+    f = fm.FMIndex(device=device.index or 0).build(S_host)  # (first build: workspace + index allocations)
+    # BASELINE.json configs[2] names fmindex_build as well (reference fmindex_build.hpp:27-34: the index of the whole text,
+    # sorted with k = 32): a second build of the same index, host text -> index resident in HBM, timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f.build(S_host)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    build_sort_ms = f._ctx.stats()["ms_total"]
     rng = np.random.default_rng(3)
     pos = rng.integers(0, n - L, Q)
     pats = S_host[pos[:, None] + np.arange(L)[None, :]]
@@ -302,13 +310,26 @@ def fm_query_leg(device, Q=1_000_000, L=32, steps=5, n=48_800_648):
     out["cpu_baseline"] = {"value": Q / dt, "unit": "queries/s", "cores": 1, "kind": "port",
                            "sample": "all %d patterns, single thread like the reference loop (fmindex_query.hpp:79-95), "
                                      "%.1f s (+ %.1f s oracle index build)" % (Q, dt, t1 - t0)}
+    from tests.fmi_layout import canonical
+    fmi = f.to_bytes()
+    out["fm_build"] = {"config": "BASELINE.json configs[2]: fmindex_build of the dm-size text (k = 32 order, SA_INTV = 4), 1 GPU",
+                       "ms": 1e3 * build_s, "value": n / build_s, "unit": "bases/s", "suffix_sort_device_ms": build_sort_ms,
+                       "region": "host text (1 byte per base) -> index arrays resident in HBM: upload, k = 32 suffix sort, "
+                                 "bwt / occ / sampled-SA kernels",
+                       "fmi_bytes": len(fmi),
+                       "fmi_equal_to_oracle": bool(canonical(fmi) == canonical(ref.serialize())),
+                       "fmi_note": "byte for byte the oracle's serialisation of the same index (fm_index.hpp:591-615), modulo the "
+                                   "reference's uninitialised pad bits (tests/fmi_layout.py)",
+                       "cpu_baseline": {"value": n / (t1 - t0), "unit": "bases/s", "cores": orc.num_threads(), "kind": "port",
+                                        "sample": "the whole dm-size text: oracle suffix sort (k = 32) + index build, %.1f s" % (t1 - t0)}}
+    del fmi
     out["parity_vs_oracle_all_patterns"] = bool(np.array_equal(r["beg"], rr["beg"]) and np.array_equal(r["end"], rr["end"])
                                                 and hits == rr["total_hits"] and r["checksum"] == rr["checksum"])
     f.close()
     return out
 
 
-def cpu_baseline(S_host_sample, k, threads=24):
+def cpu_baseline(S_host_sample, k, threads=24, whole=False):
     """Times the CPU path on a bounded sample, on the GPU box's host cores.  Reported baseline, not the optimisation
     target.  Preferred: oracle/_ref/libkiss_ref.so ("reference": the reference's OWN get_lms, PackedDNAString loads,
     put_lms_suffix and induced_sort compiled unmodified from its sources, with its OpenMP block scheduling, at the
@@ -324,15 +345,16 @@ def cpu_baseline(S_host_sample, k, threads=24):
         ref.suffix_sort(S_host_sample, k, T=T)
         dt = time.time() - t0
         return {"value": n / dt, "unit": "bases/s", "cores": T, "kind": "reference",
-                "sample": "first %d bases of the same synthetic text, k=%d, %.1f s; oracle/_ref: reference get_lms + "
+                "sample": "%s %d bases of the same synthetic text, k=%d, %.1f s; oracle/_ref: reference get_lms + "
                           "put_lms_suffix + induced_sort compiled unmodified, LMS sort (kiss1_core.hpp:41-144, needs "
-                          "spdlog) restated in oracle/ref_driver.cpp" % (n, k, dt)}
+                          "spdlog) restated in oracle/ref_driver.cpp" % ("the WHOLE text, all" if whole else "first", n, k, dt)}
     orc = oracle_binding.load()
     t0 = time.time()
     orc.suffix_sort(S_host_sample, k)
     dt = time.time() - t0
     return {"value": n / dt, "unit": "bases/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": "first %d bases of the same synthetic text, k=%d, %.1f s (oracle/_ref not present)" % (n, k, dt)}
+            "sample": "%s %d bases of the same synthetic text, k=%d, %.1f s (oracle/_ref not present)" % (
+                "the WHOLE text, all" if whole else "first", n, k, dt)}
 
 
 EXIT_TOO_FEW_DEVICES = 3  # a rank found fewer visible GPUs than --gpus: never retried, never a silent 1-GPU number
@@ -512,6 +534,40 @@ def assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof
     return out
 
 
+# 1-GPU phase times of the headline configuration (ms; DESIGN.md 4, round 4 records) and the xGMI rate DESIGN.md 7 prices
+# the two data-path transfers at: the inputs of the expected strong-scaling curve
+MODEL_1GPU_MS = {"pack": 0.6, "classify": 5.3, "sort": 52.0, "induce": 21.5, "histogram": 3.4, "partition": 5.6}
+MODEL_LINK_GBPS = 153.0
+MODEL_LMS_FRACTION = 0.2906  # LMS suffixes per base of the synthetic chm13-size text (905 939 973 / 3 117 292 070)
+
+
+def scaling_model(G, n, m=None):
+    """DESIGN.md 7's expected curve for G GPUs of one node, as numbers a measured line can be checked against: the sharded
+    phases divide by G, the all-to-all moves 12 B per LMS suffix ((G-1)/G of every rank's share over its G-1 links at
+    once), the gather moves 8 B per LMS suffix into rank 0 over its G-1 links, pack and induction stay on one GPU.  The
+    phase times are those of the chm13-size text scaled by n; NO multi-GPU run has confirmed any of it yet."""
+    m = float(m) if m else MODEL_LMS_FRACTION * n
+    scale = n / float(CHM13_N)
+    t = {kk: v * scale for kk, v in MODEL_1GPU_MS.items()}
+    link = MODEL_LINK_GBPS * 1e9
+    if G > 1:
+        exchange_bytes_per_rank = 12.0 * m / G * (G - 1) / G
+        exchange_ms = 1e3 * exchange_bytes_per_rank / ((G - 1) * link)
+        gather_bytes = 8.0 * m * (G - 1) / G
+        gather_ms = 1e3 * gather_bytes / ((G - 1) * link)
+        sharded_ms = (t["classify"] + t["histogram"] + t["partition"] + t["sort"]) / G + 0.3
+    else:
+        exchange_bytes_per_rank = gather_bytes = exchange_ms = gather_ms = 0.0
+        sharded_ms = t["classify"] + t["sort"] + 0.3
+    serial_ms = t["pack"] + t["induce"]
+    return {"gpus": G, "expected_ms": sharded_ms + exchange_ms + gather_ms + serial_ms,
+            "sharded_phases_ms": sharded_ms, "exchange_ms": exchange_ms, "gather_ms": gather_ms, "serial_on_rank0_ms": serial_ms,
+            "exchange_bytes_per_rank": exchange_bytes_per_rank, "gather_bytes_into_rank0": gather_bytes,
+            "link_GBps_assumed": MODEL_LINK_GBPS, "one_gpu_phase_ms": t,
+            "ceiling_speedup": (t["pack"] + t["classify"] + t["sort"] + t["induce"]) / serial_ms,
+            "status": "model only: no run on more than one GPU has been available to check it (DESIGN.md 7)"}
+
+
 def exact_order_leg(ctx, S, SA, n, stream, steps=3):
     """BASELINE.json configs[3]: the same text, k = -1 (unbounded) through PREFIX_DOUBLING -- the bounded phase + rank
     doubling over the tied suffixes; the result is THE suffix array, proven on the device after the timed steps."""
@@ -537,6 +593,32 @@ def exact_order_leg(ctx, S, SA, n, stream, steps=3):
             "verified": bool(rep["ok"]), "verify": {"exact": rep["exact"], "order_violations": rep["order_violations"],
                                                     "duplicates": rep["duplicates"], "ms": rep["ms"]},
             "sa_digest": "%016x" % rep["digest"], "workspace_bytes": ctx.workspace_bytes()}
+
+
+def sensitivity_leg(ctx, SA, n, k, seed, device, stream, steps=2):
+    """The same configuration on the `--harsh` text (6 % of the bases in tandem arrays of up to 30 Mb, a third of them
+    alpha-satellite-like higher-order repeats: the closest stand-in this generator has for chm13's centromeres), beside the
+    headline text's 3 %: what the satellite content costs.  Verified on the device like the headline run."""
+    import torch
+    S = gen_text_device(n, seed, device, harsh=True)
+    ctx.set_profiling(False)
+    ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.suffix_sort_dev(S.data_ptr(), n, SA.data_ptr(), k=k, stream=stream)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    st = ctx.stats()
+    rep = ctx.verify_sa_dev(S.data_ptr(), n, SA.data_ptr(), k)
+    out = {"text": "--harsh: tandem arrays 6 % of the text, up to 30 Mb each, a third as 12 x 171-base higher-order repeats",
+           "ms_per_step": 1e3 * el, "value": n / el, "unit": "bases/s", "steps": steps, "lms_rounds": st["lms_rounds"],
+           "stage_ms": {"lms_sort": st["ms_lms_sort"], "induce": st["ms_induce"], "classify": st["ms_classify"]},
+           "verified": bool(rep["ok"]), "verify": {"order_violations": rep["order_violations"], "duplicates": rep["duplicates"],
+                                                   "tied_pairs": rep["tied_pairs"]},
+           "sa_digest": "%016x" % rep["digest"], "workspace_bytes": ctx.workspace_bytes()}
+    del S
+    return out
 
 
 def dm_leg(ctx_factory, device, k=256, threads=24):
@@ -606,7 +688,7 @@ def main():
     ap.add_argument("--iid", action="store_true", help="i.i.d. text instead of the genome-like generator")
     ap.add_argument("--harsh", action="store_true",
                     help="sensitivity run: 6 %% of the text in tandem arrays up to 30 Mb incl. higher-order repeats")
-    ap.add_argument("--cpu-sample", type=int, default=1_500_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=CHM13_N,
                     help="bases of the CPU baseline sample (0 = skip); 1.5e9 bases = ~15 s of oracle/_ref time at 24 threads")
     ap.add_argument("--no-profile", action="store_true", help="do not time kernel classes with HIP events")
     ap.add_argument("--sharded-timings", action="store_true",
@@ -633,6 +715,7 @@ def main():
     ap.add_argument("--no-fm", action="store_true", help="skip the FM-index queries/s leg (single GPU only)")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-order leg (BASELINE configs[3]; single GPU only)")
     ap.add_argument("--no-dm", action="store_true", help="skip the dm-size leg (BASELINE configs[0]; single GPU only)")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the --harsh text beside the headline one (single GPU only)")
     ap.add_argument("--exact-steps", type=int, default=3)
     ap.add_argument("--fm-text-len", type=int, default=DM_N, help="text length of the FM-index leg (default: dm size)")
     ap.add_argument("--fm-queries", type=int, default=1_000_000)
@@ -792,6 +875,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # sharded runs: ONE extra step after the timed region with a device synchronisation at every phase boundary (what
+    # --sharded-timings does to every step): rank 0's phase times, the inputs of DESIGN.md 7's expected-curve table, in every
+    # N > 1 line -- so that a measured curve can be checked against the model phase by phase
+    phase_extra = None
+    if sharded and phase_ms is None:
+        phase_extra = {}
+        multi_gpu.sharded_suffix_sort(backend, n, SA=SA if rank == 0 else None, timings=phase_extra)
+        barrier()
+
     # per-class breakdown: every class timed, outside the timed region
     prof_agg, prof_steps = agg, args.steps
     if not args.no_profile and not args.profile_all and args.profile_steps > 0 and not sharded:
@@ -814,6 +906,11 @@ def main():
         out = assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof_steps, stage, last_stats,
                             ctx.workspace_bytes(), phase_ms=phase_ms, sharded_error=sharded_error, data=data,
                             text_desc=text_desc)
+        if phase_extra:
+            out["config"]["sharded_phase_ms_rank0"] = dict(phase_extra)
+            out["config"]["sharded_phase_ms_from"] = "one extra step after the timed region, phases closed by device synchronisations"
+        if sharded:
+            out["config"]["scaling_model"] = scaling_model(world, n, last_stats["m"] if world == 1 else None)
         if multi is not None:
             out["config"]["parallelism"] = ("ONE process driving devices %s through kiss_hip_multi_* (LMS sort sharded by key "
                                             "range, peer copies, induction on the first device)" % args.multi_abi)
@@ -837,11 +934,16 @@ def main():
             out["exact_order"] = exact_order_leg(ctx, S, SA, n, stream, steps=args.exact_steps)
             if not out["exact_order"]["verified"]:
                 status = EXIT_VERIFY_FAILED
+        if single and not args.no_sensitivity and not args.harsh and not args.iid and data != "file" and not algo:
+            # (after the CPU copy of the headline text is taken below would need S twice: the harsh text replaces nothing)
+            out["sensitivity"] = {"harsh": sensitivity_leg(ctx, SA, n, k, args.seed, device, stream)}
+            if not out["sensitivity"]["harsh"]["verified"]:
+                status = EXIT_VERIFY_FAILED
         # the CPU baseline: rank 0's host cores, at every N (the other ranks wait at the closing barrier)
         if args.cpu_sample > 0:
             ns = min(n, args.cpu_sample)
             sample = S[:ns].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(sample, k)
+            out["cpu_baseline"] = cpu_baseline(sample, k, whole=(ns == n))
             del sample
         else:
             out["cpu_baseline"] = None

@@ -157,10 +157,15 @@ int kiss_hip_ctx_release_io_buffers(kiss_hip_ctx *ctx);
  *   S  : n bytes, each in 0..3 (A C G T), host memory.  Only the low 2 bits are used.
  *   k  : order; 0xFFFFFFFF (the CLI's -k -1) or any k >= n means the exact suffix array.
  *   SA : caller-allocated, n+1 entries; SA[0] = n (sentinel), SA[1..n] a permutation.
- * One-shot: creates a ctx on `device`, uploads, sorts, downloads, frees.
+ * One-shot: uploads, sorts and downloads on a context the library keeps for `device` between one-shot calls (created by
+ * the first call, grown when a longer text arrives; a chm13-size context is 77 GB of work arrays and the reference's
+ * facade allocates its 5 bytes per base per call too, kiss1_core.hpp:243-257 -- at 30 bytes per base that is not free).
+ * One one-shot call at a time per device; kiss_hip_release_cached_contexts() gives the memory back.
  * n == 0 yields SA = {0} (kiss1_core.hpp:237-238).
  */
 int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device);
+/* frees the contexts the one-shot calls keep (all devices); the next one-shot call creates one again */
+int kiss_hip_release_cached_contexts(void);
 
 /* Same, on an existing ctx with host buffers (upload + sort + download).  The device-side copies of S and SA belong
  * to the ctx (allocated on the first call, kept for the next ones).  Page-locked host buffers (hipHostMalloc /

@@ -117,9 +117,12 @@ def load(hooks=None):
             "%s not built at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C kiss_amd/csrc`; there is no CPU fallback" % (os.path.basename(path), path))
     lib = ctypes.CDLL(path)
-    lib.kiss_hip_has_hooks.restype = ctypes.c_int
-    if bool(lib.kiss_hip_has_hooks()) != hooks:
-        raise ImportError("%s is not the %s build" % (path, "hooks" if hooks else "default"))
+    if hasattr(lib, "kiss_hip_has_hooks"):  # (a variant named by KISS_AMD_LIB_PATH may be a build of an earlier round)
+        lib.kiss_hip_has_hooks.restype = ctypes.c_int
+        if bool(lib.kiss_hip_has_hooks()) != hooks:
+            raise ImportError("%s is not the %s build" % (path, "hooks" if hooks else "default"))
+    elif hooks:
+        raise ImportError("%s is not a hooks build" % path)
     vp, u8p = ctypes.c_void_p, ctypes.c_void_p
     lib.kiss_hip_version.restype = ctypes.c_int
     lib.kiss_hip_strerror.restype = ctypes.c_char_p
@@ -229,5 +232,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_multi_create", "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32",
     "kiss_hip_multi_suffix_sort_dna_u32_dev", "kiss_hip_multi_get_stats", "kiss_hip_multi_ctx",
     "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters", "kiss_hip_debug_fail_alloc_over",
-    "kiss_hip_has_hooks",
+    "kiss_hip_has_hooks", "kiss_hip_release_cached_contexts",
 ]

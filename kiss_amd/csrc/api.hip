@@ -66,13 +66,16 @@ void kiss_opts_refresh(kiss_hip_ctx *ctx)
     o.no_pivot_rounds = env_on("KISS_HIP_NO_PIVOT_ROUNDS");
     o.pivot_from_round2 = env_on("KISS_HIP_PIVOT_FROM_ROUND2");
     o.pair_keys = env_on("KISS_HIP_PAIR_KEYS");
+    o.no_pair_diag = env_on("KISS_HIP_NO_PAIR_DIAG");
     o.no_fc0_onepass = env_on("KISS_HIP_NO_FC0_ONEPASS");
     o.no_pivot_ctx = env_on("KISS_HIP_NO_PIVOT_CTX");
+    o.fc0_form = (int)env_u64("KISS_HIP_FC0_FORM", 2);
     o.no_taint = env_on("KISS_HIP_NO_TAINT");
     o.isa_direct = env_on("KISS_HIP_ISA_DIRECT");
     o.no_onesweep = env_on("KISS_HIP_NO_ONESWEEP");
     o.merge_lms = env_on("KISS_HIP_MERGE_LMS");
     o.no_small_alphabet = env_on("KISS_HIP_NO_SMALL_ALPHABET");
+    o.induce_one_pass = env_on("KISS_HIP_INDUCE_ONE_PASS");
     o.verify = env_on("KISS_HIP_VERIFY");
     o.no_prefault = env_on("KISS_HIP_NO_PREFAULT");
     o.doubling_h0 = (uint32_t)env_u64("KISS_HIP_DOUBLING_H0", 0);
@@ -235,7 +238,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
 void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
-    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts,
+    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts, ctx->ind_desc,
                     ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->near_tmp2, ctx->pairs1, ctx->pairs2, ctx->rx_ctl, ctx->refine_heads, ctx->ga_codes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -270,6 +273,9 @@ int sort_dev(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, uint32_t k, int 
 {
     if (!ctx) return KISS_HIP_E_INVALID;
     kiss_opts_refresh(ctx);
+#ifdef KISS_NO_DEVICE_LOCK // (variant build of the A-B of DESIGN.md 4.2: the shipped code without the lock)
+    return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
+#endif
     if (ctx->opts.no_serialize) return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
     std::lock_guard<std::mutex> lock(kiss_device_mutex(ctx->device));
     return sort_dev_unlocked(ctx, d_S, n, k, algo, d_SA, stream);
@@ -461,7 +467,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
         ctx->rx_tiles_cap = m_cap / 16384 + 2;
         ALLOC(rx_desc, 256 * ctx->rx_tiles_cap);
         ALLOC(rx_ghist, 256 * 12);
-        ctx->fc_desc_cap = m_cap / 8192 + 4;
+        ctx->fc_desc_cap = m_cap / 2048 + 4; // (room for the 2048-item tiles of the smallest one-pass form)
         ALLOC(fc_desc, ctx->fc_desc_cap);
 #undef ALLOC
         // descriptors carry the epoch of the pass that wrote them: cleared once, never again (the epoch keeps counting)
@@ -684,6 +690,12 @@ int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, ui
         ALLOC(tile_cnt, ctx->n_tiles_cap);
         ALLOC(d_counts, 16);
         ALLOC(ind_counts, ctx->ind_tiles_cap);
+        ctx->ind_desc_stride = (max_n + 1) / 1024 + 2;
+        ALLOC(ind_desc, 4 * ctx->ind_desc_stride);
+        if (hipMemset(ctx->ind_desc, 0, 4 * ctx->ind_desc_stride * sizeof(uint64_t)) != hipSuccess) {
+            rc = KISS_HIP_E_HIP;
+            break;
+        }
         ALLOC(rx_ctl, 4); // [0] radix ticket, [1] look-back error flag
         if (hipMemset(ctx->rx_ctl, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
             rc = KISS_HIP_E_HIP;
@@ -797,6 +809,40 @@ int kiss_hip_ctx_suffix_sort_dna_u32(kiss_hip_ctx *ctx, const uint8_t *S, uint64
                           &a);
 }
 
+// ---- one-shot calls (the form the C++ facade KissHipSorter binds, kiss_hip_sorter.hpp) ------------------------------------
+// A context for a chm13-size text is 77 GB of work arrays + 15.6 GB of text / SA copies: allocating and freeing that per
+// call costs more than the sort.  The one-shot entry points keep ONE context per device between calls (grown when a longer
+// text arrives, never shrunk) and hand it back through kiss_hip_release_cached_contexts().  One one-shot call at a time per
+// device (a sort fills the GPU; the reference's static facade is not re-entrant either).
+namespace {
+struct CachedCtx {
+    std::mutex m;
+    kiss_hip_ctx *ctx = nullptr;
+};
+CachedCtx *cached_ctx(int device)
+{
+    static CachedCtx c[64];
+    return &c[(unsigned)device & 63u];
+}
+// the device's cached context, grown to hold n bases (lock held by the caller)
+int cached_ctx_for(CachedCtx &c, int device, uint64_t n, kiss_hip_ctx **out)
+{
+    if (c.ctx && c.ctx->max_n < n) {
+        kiss_hip_ctx_destroy(c.ctx);
+        c.ctx = nullptr;
+    }
+    if (!c.ctx) {
+        int rc = kiss_hip_ctx_create(&c.ctx, device, n);
+        if (rc) {
+            c.ctx = nullptr;
+            return rc;
+        }
+    }
+    *out = c.ctx;
+    return KISS_HIP_OK;
+}
+} // namespace
+
 int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int algo, uint32_t *SA, int device)
 {
     if (!SA || (n && !S)) return KISS_HIP_E_INVALID;
@@ -804,12 +850,31 @@ int kiss_hip_suffix_sort_dna_u32(const uint8_t *S, uint64_t n, uint32_t k, int a
         SA[0] = 0;
         return KISS_HIP_OK;
     }
+    if (device < 0 || device >= 64) return KISS_HIP_E_NO_DEVICE;
+    CachedCtx &c = *cached_ctx(device);
+    std::lock_guard<std::mutex> lock(c.m);
     kiss_hip_ctx *ctx = nullptr;
-    int rc = kiss_hip_ctx_create(&ctx, device, n);
+    int rc = cached_ctx_for(c, device, n, &ctx);
     if (rc) return rc;
     rc = kiss_hip_ctx_suffix_sort_dna_u32(ctx, S, n, k, algo, SA);
-    kiss_hip_ctx_destroy(ctx);
+    if (rc == KISS_HIP_E_NOMEM || rc == KISS_HIP_E_HIP) { // do not keep a context that may be half grown or on a faulted device
+        kiss_hip_ctx_destroy(c.ctx);
+        c.ctx = nullptr;
+    }
     return rc;
+}
+
+int kiss_hip_release_cached_contexts(void)
+{
+    for (int d = 0; d < 64; d++) {
+        CachedCtx &c = *cached_ctx(d);
+        std::lock_guard<std::mutex> lock(c.m);
+        if (c.ctx) {
+            kiss_hip_ctx_destroy(c.ctx);
+            c.ctx = nullptr;
+        }
+    }
+    return KISS_HIP_OK;
 }
 
 /* ---- test hooks: the sorting / scanning primitives on caller data (host pointers) ---------------------- */

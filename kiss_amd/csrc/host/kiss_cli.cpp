@@ -273,6 +273,13 @@ int suffix_sort_main(const Args &a)
     kiss_hip_multi *mc = nullptr;
     double multi_create_s = 0;
     if (multi) { // one process, several devices: the per-device contexts come first, the first one also loads the file
+        // Two distinct GPUs exchange the whole LMS list and gather half of the sorted list over the ONE xGMI link between
+        // them: the phase model (bench.py: scaling_model) puts a chm13-size sort at about 97 ms on two GPUs
+        // against 80 ms on one.  The result is the same; the user is told that the second GPU does not pay.
+        if (a.devices.size() == 2 && a.devices[0] != a.devices[1])
+            std::fprintf(stderr, "[warning] --gpus 2: two GPUs share one xGMI link for the exchange of the LMS list and the gather of the "
+                                 "sorted pieces; the phase model expects this to be SLOWER than one GPU (about 0.8x; 4 GPUs: about "
+                                 "1.4x, 8 GPUs: about 2.1x).  Same result either way.\n");
         uint64_t bytes = 0;
         if (kiss_hip_file_size(a.fasta.c_str(), &bytes) != KISS_HIP_OK) throw std::runtime_error("cannot open " + a.fasta);
         const auto tc = std::chrono::steady_clock::now();

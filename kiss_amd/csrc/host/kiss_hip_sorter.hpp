@@ -10,6 +10,7 @@
 // nothing C++ crosses the ABI itself.  `num_threads` is accepted and ignored (no result depends on it).
 #pragma once
 #include <cstdint>
+#include <mutex>
 #include <new>
 #include <ranges>
 #include <stdexcept>
@@ -42,17 +43,42 @@ struct KissHipSorter {
     }
   }
 
-  static int& device() {
-    static int d = 0;
-    return d;
+  // Which GPU(s) the static facade sorts on: process-wide configuration like the reference's own globals (tbb::global_control,
+  // the default logger), but safe to set from one thread while others sort -- a call takes a copy under the lock.
+  //   set_device(d)         one GPU (default: device 0)
+  //   set_devices({0,1,..}) the LMS sort sharded over these GPUs of the node by this process
+  //                         (kiss_hip_suffix_sort_dna_u32_multi; the induction runs on the first one) -- what
+  //                         `kiss suffix_sort --gpus N` selects; an empty list goes back to one GPU
+  struct Config {
+    int device = 0;
+    std::vector<int> devices;
+  };
+  static void set_device(int d) {
+    std::lock_guard<std::mutex> lock(config_mutex());
+    config_ref().device = d;
   }
-  // non-empty: the LMS sort is sharded over these GPUs of the node by this process (kiss_hip_suffix_sort_dna_u32_multi;
-  // the induction runs on the first one) -- what `kiss suffix_sort --gpus N` selects
-  static std::vector<int>& devices() {
-    static std::vector<int> d;
-    return d;
+  static void set_devices(std::vector<int> d) {
+    std::lock_guard<std::mutex> lock(config_mutex());
+    config_ref().devices = std::move(d);
+  }
+  static Config config() {
+    std::lock_guard<std::mutex> lock(config_mutex());
+    return config_ref();
+  }
+  static int device() { return config().device; }
+  static std::vector<int> devices() { return config().devices; }
+
+ private:
+  static std::mutex& config_mutex() {
+    static std::mutex m;
+    return m;
+  }
+  static Config& config_ref() {
+    static Config c;
+    return c;
   }
 
+ public:
   static void check(int rc, const char* where) {
     if (rc == KISS_HIP_OK) return;
     if (rc == KISS_HIP_E_NOMEM) throw std::bad_alloc{};
@@ -73,13 +99,14 @@ struct KissHipSorter {
                                    int algo = KISS_HIP_ALGO_PARALLEL_SORTING) {
     // an order beyond 32 bits is the unbounded order (the CLI truncates -1 to 0xFFFFFFFF, suffix_sort.hpp:35-37)
     const std::uint32_t k32 = static_cast<std::uint64_t>(k) > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<std::uint32_t>(k);
+    const Config cfg = config();
     return with_u32(S.size(), [&](std::uint32_t* SA) {
-      if (!devices().empty())
-        check(kiss_hip_suffix_sort_dna_u32_multi(S.data(), S.size(), k32, algo, SA, devices().data(),
-                                                 static_cast<int>(devices().size())),
+      if (!cfg.devices.empty())
+        check(kiss_hip_suffix_sort_dna_u32_multi(S.data(), S.size(), k32, algo, SA, cfg.devices.data(),
+                                                 static_cast<int>(cfg.devices.size())),
               "kiss_hip_suffix_sort_dna_u32_multi");
       else
-        check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k32, algo, SA, device()), "kiss_hip_suffix_sort_dna_u32");
+        check(kiss_hip_suffix_sort_dna_u32(S.data(), S.size(), k32, algo, SA, cfg.device), "kiss_hip_suffix_sort_dna_u32");
     });
   }
 

@@ -371,6 +371,233 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
     }
 }
 
+// ---- count-free form: ONE pass per source segment -------------------------------------------------------------------
+// k_induce_count read the segment once only to learn how many items of each class every tile holds; a scan turned the
+// counts into offsets and k_induce_scatter read the segment again.  The scatter computes the same counts on its way (it
+// ranks its items by class), so a tile can find the items of each class in all EARLIER tiles by a decoupled look-back
+// instead: tiles take their number from an atomic ticket (every predecessor of a running tile is running or done),
+// publish their four class counts, and wave c of the workgroup sums class c over the predecessors, 64 descriptors per
+// round trip, until it meets a tile that has published its running total -- the scheme of k_fc0_onepass (lms_sort.hip)
+// with the descriptor of the radix passes: [status:2 | pass epoch:30 | value:32], one 64-bit word per (class, tile), never
+// cleared (the epoch keeps counting).  The count kernel, the three scan launches and their 4 bytes per item are gone
+// (round 3: 5.1 ms of 21 per sort); the wait is bounded (error flag, not a hung GPU).
+constexpr uint32_t IN_SPIN_LIMIT = 1u << 22;
+static_assert(IN_WAVES == 4, "wave c of a partition tile walks class c");
+
+__device__ __forceinline__ uint32_t in_lookback(uint64_t *__restrict__ d, uint32_t tile, uint32_t mine, uint64_t tag,
+                                                uint32_t *__restrict__ err)
+{
+    const uint32_t lane = lane_id();
+    constexpr uint64_t TAGMASK = 0x3FFFFFFFull << 32;
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&d[0], (2ull << 62) | tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0u;
+    }
+    if (lane == 0) __hip_atomic_store(&d[tile], (1ull << 62) | tag | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0, spins = 0;
+    int64_t base = (int64_t)tile;
+    for (;;) {
+        const int64_t t = base - 1 - (int64_t)lane;
+        uint64_t v = t >= 0 ? __hip_atomic_load(&d[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((2ull << 62) | tag);
+        if ((v & TAGMASK) != tag) v = 0; // a word of an earlier pass: not published yet
+        const uint32_t st = (uint32_t)(v >> 62);
+        const uint64_t incl = __ballot(st == 2u), ready = __ballot(st != 0u);
+        const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;    // nearest running total
+        const uint64_t need = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0 .. first
+        if ((ready & need) != need) { // a predecessor this side of it has not published yet
+            if (++spins > IN_SPIN_LIMIT) {
+                if (lane == 0) *err = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        uint32_t a = lane <= first ? (uint32_t)v : 0u;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd, 64);
+        excl += a;
+        if (first < 64u) break;
+        base -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&d[tile], (2ull << 62) | tag | (uint64_t)(uint32_t)(excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <bool REMAP>
+__global__ __launch_bounds__(IN_THREADS) void k_induce_onepass(const uint64_t *__restrict__ pk, const uint32_t *srcP,
+                                                              uint32_t *srcC, int64_t beg, uint64_t N, int dir,
+                                                              uint32_t emitmask, uint64_t tiles, DstPos dst, uint32_t *SA,
+                                                              uint32_t *CTX, uint32_t *__restrict__ totals, LmsRemap rm,
+                                                              uint64_t *__restrict__ desc, uint64_t desc_stride,
+                                                              uint32_t *__restrict__ ctl, uint32_t ticket_base, uint64_t epoch)
+{
+    __shared__ uint32_t wtot[IN_WAVES][4];
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_excl[4];
+    __shared__ uint32_t stP[IN_TILE], stC[IN_TILE];
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ctl[2], 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= tiles) return; // (never: the grid is `tiles` workgroups)
+    const int wave = threadIdx.x >> 6;
+    struct __attribute__((packed, aligned(4))) U4 {
+        uint32_t v[4];
+    };
+    const uint64_t i0 = (uint64_t)tile * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
+    uint32_t vv[IN_ITEMS], cc[IN_ITEMS], rr[IN_ITEMS]; // rr = (class << 28) | rank in wave
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    int64_t shift = 0; // REMAP (dir > 0 only): see k_induce_count
+    bool block = i0 + IN_ITEMS <= N;
+    if (REMAP) {
+        const uint64_t tj = (uint64_t)beg + (uint64_t)tile * IN_TILE;
+        const uint32_t t0 = remap_below_wave(rm, tj), t1 = remap_below_wave(rm, tj + IN_TILE);
+        if (t0 == t1) shift = (int64_t)t0;
+        else if (block) {
+            const uint32_t b0 = remap_below(rm, (uint64_t)beg + i0);
+            block = b0 == remap_below(rm, (uint64_t)beg + i0 + IN_ITEMS);
+            shift = (int64_t)b0;
+        }
+    }
+    if (block) {
+        const int64_t p0 = (dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1)) - shift; // lowest address of my items
+        uint32_t bp[IN_ITEMS], bc[IN_ITEMS];
+#pragma unroll
+        for (int q = 0; q < IN_ITEMS / 4; q++) {
+            const U4 tp = *reinterpret_cast<const U4 *>(srcP + p0 + 4 * q);
+            const U4 tcw = *reinterpret_cast<const U4 *>(srcC + p0 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                bp[4 * q + e] = tp.v[e];
+                bc[4 * q + e] = tcw.v[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < IN_ITEMS; e++) {
+            const int a = dir > 0 ? e : IN_ITEMS - 1 - e; // place of item e inside the block
+            uint32_t v = bp[a], c = bc[a], cls;
+            if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm); // refresh path
+            else {
+                const uint32_t pc = c & 3u;
+                cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+            }
+            uint32_t local = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (cls == (uint32_t)k) local = cnt[k];
+                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
+            }
+            vv[e] = v;
+            cc[e] = c;
+            rr[e] = (cls << 28) | local;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < IN_ITEMS; e++) {
+            const uint64_t i = i0 + (uint64_t)e;
+            uint32_t cls = 4u, v = 0, c = 0;
+            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &c, rm);
+            uint32_t local = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (cls == (uint32_t)k) local = cnt[k];
+                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
+            }
+            vv[e] = v;
+            cc[e] = c;
+            rr[e] = (cls << 28) | local;
+        }
+    }
+    uint32_t run[4]; // wave totals
+    uint32_t lex[4]; // items of class k in lower lanes
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t inc = cnt[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if ((int)lane_id() >= d) inc += o;
+        }
+        lex[k] = inc - cnt[k];
+        run[k] = __shfl(inc, 63, 64);
+    }
+#pragma unroll
+    for (int e = 0; e < IN_ITEMS; e++) {
+        const uint32_t cls = rr[e] >> 28;
+        if (cls < 4u) rr[e] += cls == 0 ? lex[0] : (cls == 1 ? lex[1] : (cls == 2 ? lex[2] : lex[3]));
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) wtot[wave][c] = run[c];
+    }
+    __syncthreads();
+    uint32_t coff[5]; // start of class c inside the staged tile
+    uint32_t woff[4]; // this wave's start inside class c
+    coff[0] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint32_t t = 0, w0 = 0;
+        for (int w = 0; w < IN_WAVES; w++) {
+            if (w < wave) w0 += wtot[w][c];
+            t += wtot[w][c];
+        }
+        woff[c] = w0;
+        coff[c + 1] = coff[c] + t;
+    }
+    // wave c: items of class c in all earlier tiles (the other waves' round trips run at the same time; the staging
+    // below does not need the answer)
+    {
+        const uint32_t mine = wave == 0 ? coff[1] - coff[0] : (wave == 1 ? coff[2] - coff[1] : (wave == 2 ? coff[3] - coff[2] : coff[4] - coff[3]));
+        const uint64_t tag = (epoch & 0x3FFFFFFFull) << 32;
+        const uint32_t ex = in_lookback(desc + (uint64_t)wave * desc_stride, tile, mine, tag, ctl + 1);
+        if (lane_id() == 0) {
+            s_excl[wave] = ex;
+            if ((uint64_t)tile + 1 == tiles) totals[wave] = ex + mine;
+        }
+    }
+    // stage the tile class by class in LDS, then write every class as one contiguous run
+#pragma unroll
+    for (int j = 0; j < IN_ITEMS; j++) {
+        const uint32_t cls = rr[j] >> 28;
+        if (cls < 4u) {
+            const uint32_t li = coff[cls] + woff[cls] + (rr[j] & 0x0FFFFFFFu);
+            stP[li] = vv[j] - 1u;
+            stC[li] = child_ctx(cc[j]);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = coff[4];
+    for (uint32_t l0 = threadIdx.x * 4u; l0 < total; l0 += IN_THREADS * 4u) {
+        const uint32_t cls = l0 < coff[1] ? 0u : (l0 < coff[2] ? 1u : (l0 < coff[3] ? 2u : 3u));
+        const uint32_t cend = cls == 0 ? coff[1] : (cls == 1 ? coff[2] : (cls == 2 ? coff[3] : coff[4]));
+        if (l0 + 4u <= cend) {
+            const uint32_t toff = s_excl[cls];
+            const uint32_t cstart = cls == 0 ? coff[0] : (cls == 1 ? coff[1] : (cls == 2 ? coff[2] : coff[3]));
+            const int64_t dp = cls == 0 ? dst.p[0] : (cls == 1 ? dst.p[1] : (cls == 2 ? dst.p[2] : dst.p[3]));
+            const int64_t d0 = dp + (int64_t)dir * (int64_t)((uint64_t)toff + (l0 - cstart)); // place of item l0; l0 + e at d0 + dir * e
+            U4 wp, wc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int a = dir > 0 ? e : 3 - e;
+                wp.v[a] = stP[l0 + e];
+                wc.v[a] = stC[l0 + e];
+            }
+            const int64_t lo = dir > 0 ? d0 : d0 - 3;
+            *reinterpret_cast<U4 *>(SA + lo) = wp;
+            *reinterpret_cast<U4 *>(CTX + lo) = wc;
+        } else {
+            for (uint32_t li = l0; li < l0 + 4u && li < total; li++) {
+                const uint32_t c2 = li < coff[1] ? 0u : (li < coff[2] ? 1u : (li < coff[3] ? 2u : 3u));
+                const uint32_t toff = s_excl[c2];
+                const uint32_t cstart = c2 == 0 ? coff[0] : (c2 == 1 ? coff[1] : (c2 == 2 ? coff[2] : coff[3]));
+                const int64_t dp = c2 == 0 ? dst.p[0] : (c2 == 1 ? dst.p[1] : (c2 == 2 ? dst.p[2] : dst.p[3]));
+                const int64_t d = dp + (int64_t)dir * (int64_t)((uint64_t)toff + (li - cstart));
+                SA[d] = stP[li];
+                CTX[d] = stC[li];
+            }
+        }
+    }
+}
+
 // ---- single-workgroup chain kernel -----------------------------------------------------
 // Processes one source segment and, when selfclass >= 0, keeps processing what it appended to that
 // class until nothing is appended any more.  out[0..3] = items appended per class, out[4] = rounds.
@@ -490,6 +717,24 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
     } else {
         const uint64_t tiles = div_up(N, IN_TILE);
         if (4 * tiles + 1 > ctx->ind_tiles_cap) return KINTERNAL();
+#ifdef KISS_HIP_HOOKS
+        if (ctx->opts.induce_one_pass && ctx->ind_desc && tiles <= ctx->ind_desc_stride && tiles < (1ull << 31)) {
+            // (hooks build, measured and dropped in round 4: DESIGN.md 4) one pass, the tiles find their offsets by look-back
+            KTimer t(ctx, KISS_HIP_K_INDUCE_SCATTER, N);
+            ctx->ind_epoch++;
+            if (remap)
+                hipLaunchKernelGGL(k_induce_onepass<true>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, sw.dir, emitmask, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->ind_desc,
+                                   ctx->ind_desc_stride, ctx->rx_ctl, ctx->ind_ticket_base, ctx->ind_epoch);
+            else
+                hipLaunchKernelGGL(k_induce_onepass<false>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, sw.dir, emitmask, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->ind_desc,
+                                   ctx->ind_desc_stride, ctx->rx_ctl, ctx->ind_ticket_base, ctx->ind_epoch);
+            KCHECK(hipGetLastError());
+            ctx->ind_ticket_base += (uint32_t)tiles;
+        } else
+#endif
+        {
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
             if (remap)
@@ -510,6 +755,7 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
                 hipLaunchKernelGGL(k_induce_scatter<false>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
                                    srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
             KCHECK(hipGetLastError());
+        }
         }
         KTRY(kiss_readback(ctx, ctx->d_small, 4));
         for (int c = 0; c < 4; c++) tot[c] = ctx->h_pinned[c];

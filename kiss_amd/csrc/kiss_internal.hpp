@@ -25,14 +25,17 @@ struct KissOpts {
     bool no_early_out = false;     // KISS_HIP_NO_EARLY_OUT
     bool no_pivot_rounds = false;  // KISS_HIP_NO_PIVOT_ROUNDS: 32-base rounds only
     bool pivot_from_round2 = false;// KISS_HIP_PIVOT_FROM_ROUND2
+    bool no_pair_diag = false;     // KISS_HIP_NO_PAIR_DIAG: tied pairs of the first refinement round by one walk each (round 3)
     bool pair_keys = false;        // KISS_HIP_PAIR_KEYS: gather the round's key for pairs as well
     bool no_fc0_onepass = false;   // KISS_HIP_NO_FC0_ONEPASS: count + scan + compact after round 0
+    int fc0_form = 2;              // KISS_HIP_FC0_FORM: 1 = the one-pass kernel of round 3 (88 VGPRs), 2 = the two-per-CU form
     bool no_pivot_ctx = false;     // KISS_HIP_NO_PIVOT_CTX
     bool no_taint = false;         // KISS_HIP_NO_TAINT: the suffix-array form compares every neighbour pair
     bool isa_direct = false;       // KISS_HIP_ISA_DIRECT: inverse SA by plain random scatter
     bool no_onesweep = false;      // KISS_HIP_NO_ONESWEEP: histogram + offsets + scatter radix passes
     bool merge_lms = false;        // KISS_HIP_MERGE_LMS: the merged copy of the LMS list (round-1 form)
     bool no_small_alphabet = false;// KISS_HIP_NO_SMALL_ALPHABET (general.hip)
+    bool induce_one_pass = false;  // KISS_HIP_INDUCE_ONE_PASS: a source segment partitioned in one pass with a look-back (slower: DESIGN.md 4)
     bool verify = false;           // KISS_HIP_VERIFY: check sums and per-bucket checks inside the induction
     bool no_prefault = false;      // KISS_HIP_NO_PREFAULT
     bool no_serialize = false;     // KISS_HIP_NO_SERIALIZE: no per-device lock around the device phase of a sort
@@ -169,6 +172,11 @@ struct kiss_hip_ctx {
     bool ctx_words_valid = false;  // CTX holds the words of the last kiss_induce on this ctx (taint bits for the exact finish)
     uint32_t *ind_counts = nullptr;// 4 x tiles + 1
     uint64_t ind_tiles_cap = 0;
+    // one-pass partition (induce.hip: k_induce_onepass): look-back descriptors, 4 classes x ind_desc_stride tiles, tagged with
+    // the pass epoch (cleared once); the tile ticket is rx_ctl[2]
+    uint64_t *ind_desc = nullptr;
+    uint64_t ind_desc_stride = 0, ind_epoch = 0;
+    uint32_t ind_ticket_base = 0;
     uint32_t *d_small = nullptr;   // small scratch (64 u32) for single-workgroup kernels
     uint32_t *h_pinned = nullptr;  // 64 u32 pinned host scratch
     // low-latency read-back of a few words (api.hip: kiss_readback): a one-wave kernel stores them into this coherent

@@ -19,18 +19,37 @@
 // same places: compared on the host after the sort (kiss_tie_trace_report).
 #ifdef KISS_HIP_HOOKS
 #define KISS_TRACE(...) __VA_ARGS__
-#define KISS_TRACE_PARAM , uint32_t *dbg
 #define KISS_TRACE_ARG(ctx) , (ctx)->tie_dbg_on ? (ctx)->tie_dbg : (uint32_t *)nullptr
+#define KISS_TT_RUNS
+#define KISS_TT_MARK
+#define KISS_TT_TABLE
 #else
 #define KISS_TRACE(...)
-#define KISS_TRACE_PARAM
-#define KISS_TRACE_ARG(ctx)
+#define KISS_TRACE_ARG(ctx) , (uint32_t *)nullptr
+#endif
+// (-DKISS_TT_RUNS / _MARK / _TABLE without the hooks: variant builds in which ONE of the three kernels is compiled as in
+//  the hooks build, recorder code and parameter included but handed a null pointer -- the A-B of DESIGN.md 4.2 that tells
+//  which kernel's generated code the fault lives in)
+#ifdef KISS_TT_RUNS
+#define KISS_TRACE_R(...) __VA_ARGS__
+#else
+#define KISS_TRACE_R(...)
+#endif
+#ifdef KISS_TT_MARK
+#define KISS_TRACE_M(...) __VA_ARGS__
+#else
+#define KISS_TRACE_M(...)
+#endif
+#ifdef KISS_TT_TABLE
+#define KISS_TRACE_T(...) __VA_ARGS__
+#else
+#define KISS_TRACE_T(...)
 #endif
 
 namespace {
 
 constexpr int PL_THREADS = 256;
-#ifdef KISS_HIP_HOOKS
+#if defined(KISS_TT_RUNS) || defined(KISS_TT_MARK) || defined(KISS_TT_TABLE)
 // trace layout (32-bit words): header [0, 16), then per near-end suffix e < TT_MAX_E
 constexpr uint32_t TT_MAX_E = 1024, TT_RUNS = 16, TT_MARK = TT_RUNS + 8 * TT_MAX_E, TT_POST = TT_MARK + 4 * TT_MAX_E,
                    TT_WORDS = TT_POST + 8 * TT_MAX_E;
@@ -305,10 +324,10 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
                                                              const uint32_t *__restrict__ far_sorted,
                                                              const uint32_t *__restrict__ near_pos,
                                                              const uint32_t *__restrict__ near_idx, uint32_t E,
-                                                             uint32_t *__restrict__ run_start KISS_TRACE_PARAM)
+                                                             uint32_t *__restrict__ run_start  KISS_TRACE_R(, uint32_t *dbg))
 {
     const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
-    KISS_TRACE(if (dbg && e == 0) { dbg[0] = E; dbg[1] = (uint32_t)k; dbg[8] = (uint32_t)wall_clock64(); })
+    KISS_TRACE_R(if (dbg && e == 0) { dbg[0] = E; dbg[1] = (uint32_t)k; dbg[8] = (uint32_t)wall_clock64(); })
     if (e >= E) return;
     const uint64_t pe = near_pos[e];
     const uint64_t hi = near_idx[e]; // far suffixes [0, hi) sort before e
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
     }
     (void)bad;
     run_start[e] = (uint32_t)lo; // far suffixes [lo, hi) tie with e
-    KISS_TRACE(if (dbg && e < TT_MAX_E) {
+    KISS_TRACE_R(if (dbg && e < TT_MAX_E) {
         uint32_t *r = dbg + TT_RUNS + 8 * e;
         const uint32_t f1 = hi >= 1 ? far_sorted[hi - 1] : 0xFFFFFFFFu, f2 = hi >= 2 ? far_sorted[hi - 2] : 0xFFFFFFFFu,
                        f3 = hi >= 3 ? far_sorted[hi - 3] : 0xFFFFFFFFu;
@@ -362,9 +381,9 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__
                                                              const uint32_t *__restrict__ near_idx,
                                                              uint32_t *__restrict__ far_ctx, uint32_t E,
                                                              uint8_t *__restrict__ hfar // optional (ctx->hfar): the far suffixes
-                                                             KISS_TRACE_PARAM) // of a run share k bases with each other too -- one group
+                                                             KISS_TRACE_M(, uint32_t *dbg)) // of a run share k bases with each other too -- one group
 {
-    KISS_TRACE(if (dbg && threadIdx.x == 0 && blockIdx.x == 0) {
+    KISS_TRACE_M(if (dbg && threadIdx.x == 0 && blockIdx.x == 0) {
         dbg[4] = E;
         dbg[5] = hfar ? 1u : 0u;
         dbg[6] = (uint32_t)wall_clock64(); // start of the first workgroup
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__
     for (uint64_t b = blockIdx.x; b < (uint64_t)NT_BLOCKS * E; b += gridDim.x) {
         const uint32_t e = (uint32_t)(b / NT_BLOCKS), sub = (uint32_t)(b % NT_BLOCKS);
         const uint64_t lo = run_start[e], hi = near_idx[e];
-        KISS_TRACE(if (dbg && threadIdx.x == 0 && e < TT_MAX_E && sub == 0) {
+        KISS_TRACE_M(if (dbg && threadIdx.x == 0 && e < TT_MAX_E && sub == 0) {
             uint32_t *q = dbg + TT_MARK + 4 * e;
             q[0] = (uint32_t)lo;
             q[1] = (uint32_t)hi;
@@ -427,11 +446,11 @@ namespace {
 __global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__restrict__ near_pos,
                                                           const uint32_t *__restrict__ near_fin, uint32_t E,
                                                           uint32_t *__restrict__ tab_fin, uint32_t *tab_pos
-                                                          KISS_TRACE(, uint32_t *dbg, const uint32_t *tt_far, const uint32_t *tt_ctx,
+                                                          KISS_TRACE_T(, uint32_t *dbg, const uint32_t *tt_far, const uint32_t *tt_ctx,
                                                                      const uint8_t *tt_hfar, const uint32_t *tt_idx))
 {
     const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
-    KISS_TRACE(
+    KISS_TRACE_T(
         if (dbg && e == 0) dbg[3] = (uint32_t)wall_clock64();
         if (dbg && e < E && e < TT_MAX_E) { // the same places again, as the kernel after the marks finds them (tab_pos[e] = run_start[e] still)
             const uint64_t hi = tt_idx[e];
@@ -496,9 +515,9 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE(, (uint32_t *)nullptr));
+                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_R(, (uint32_t *)nullptr));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE(, (uint32_t *)nullptr));
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_M(, (uint32_t *)nullptr));
             }
             ctx->near_form = 2;
             ctx->near_sorted = near_sorted;
@@ -523,13 +542,13 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
                 hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_ARG(ctx));
+                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_R(KISS_TRACE_ARG(ctx)));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
-                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_ARG(ctx));
+                                   ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_M(KISS_TRACE_ARG(ctx)));
             }
             // (stream order: k_near_tie_mark has read near_tmp2 before the table overwrites it)
             hipLaunchKernelGGL(k_near_table, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, near_pos, ctx->near_fin, E, ctx->near_tmp,
-                               ctx->near_tmp2 KISS_TRACE_ARG(ctx) KISS_TRACE(, ctx->lms_sorted_far, ctx->lms_ctx_far,
+                               ctx->near_tmp2 KISS_TRACE_T(KISS_TRACE_ARG(ctx), ctx->lms_sorted_far, ctx->lms_ctx_far,
                                               (k == ctx->h_depth) ? ctx->hfar : (const uint8_t *)nullptr, ctx->near_idx));
             ctx->near_form = 1;
             ctx->rm_fin = ctx->near_tmp;

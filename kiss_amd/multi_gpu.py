@@ -50,7 +50,7 @@ class GpuBackend:
         self.ctx, self.S, self.k = ctx, S, int(k) & 0xFFFFFFFF
         self.n = int(S.numel())
         self.dev = S.device
-        self.lib = _lib.load()
+        self.lib = getattr(ctx, "_lib", None) or _lib.load()  # the library that made the context (default or hooks build)
         self._views = {}
 
     def _sync(self):

@@ -31,9 +31,9 @@ int main(int argc, char** argv) {
     for (std::size_t i = 0; i < S.size(); i++) text[i] = (char)('A' + S[i]);
     auto sc = biovoltron::KissHipSorter<>::get_suffix_array(std::string_view(text), 256u, 1);
     // the same sort sharded over two shares of device 0 by this process (what `kiss suffix_sort --gpus N` selects)
-    biovoltron::KissHipSorter<>::devices() = {0, 0};
+    biovoltron::KissHipSorter<>::set_devices({0, 0});
     auto sd = biovoltron::KissHipSorter<>::get_suffix_array_dna(S, 256u, 1);
-    biovoltron::KissHipSorter<>::devices().clear();
+    biovoltron::KissHipSorter<>::set_devices({});
     // 64-bit size_type: the same values, widened
     auto s64 = biovoltron::KissHipSorter<std::uint64_t>::get_suffix_array_dna(S, 256u, 1);
     if (s64.size() != sa.size()) return 5;

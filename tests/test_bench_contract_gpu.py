@@ -58,8 +58,14 @@ def test_bench_single_gpu_line():
     cd = out["cpu_baseline_dm"]
     if cd is not None:
         assert cd["kind"] == "reference" and cd["value"] > 0 and d["hip"]["sa_equal_to_reference_pipeline"] is True
-    # FM leg: range and locate kernels timed apart
+    # FM leg: range and locate kernels timed apart; the index build (configs[2] names fmindex_build) timed and its .fmi
+    # bytes equal to the oracle's serialisation
     assert fq["range_kernel_ms"] > 0 and fq["locate_kernel_ms"] >= 0
+    fb = fq["fm_build"]
+    assert fb["ms"] > 0 and fb["fmi_equal_to_oracle"] is True and fb["fmi_bytes"] > 0 and fb["cpu_baseline"]["value"] > 0
+    # the satellite-rich text beside the headline one, verified like it
+    h = out["sensitivity"]["harsh"]
+    assert h["verified"] is True and h["ms_per_step"] > 0 and h["workspace_bytes"] > 0 and len(h["sa_digest"]) == 16
 
 
 @pytest.mark.gpu

@@ -304,6 +304,24 @@ def test_round2_shortcuts_equal_the_forms_they_replace(hctx, oracle, monkeypatch
         c.close()
 
 
+def test_one_pass_induction_equals_count_scan_scatter(hctx, oracle, monkeypatch):
+    # round 4, measured and dropped: a source segment of the induction partitioned in ONE pass, the tiles finding
+    # the class counts of their predecessors by look-back (induce.hip: k_induce_onepass, KISS_HIP_INDUCE_ONE_PASS in the hooks
+    # build) instead of count kernel + scan + scatter.  Same suffix array, also on runs of one base (chains of self-feeding
+    # passes), on a text whose passes have thousands of tiles, and in exact order.
+    import kiss_amd
+    texts = [gen.genome_like(5_000_000, 41), np.zeros(300_000, np.uint8), gen.periodic(600_000, 3, 9, mutations=25),
+             np.repeat(gen.iid(40_000, 6), 17)]
+    for S in texts:
+        for k, algo in ((256, 0), (kiss_amd.K_UNBOUNDED, 1)):
+            want = oracle.suffix_sort(S, k)
+            monkeypatch.delenv("KISS_HIP_INDUCE_ONE_PASS", raising=False)
+            assert np.array_equal(hctx.suffix_sort(S, k, algo=algo), want), (S.size, k, "count + scan + scatter")
+            monkeypatch.setenv("KISS_HIP_INDUCE_ONE_PASS", "1")
+            assert np.array_equal(hctx.suffix_sort(S, k, algo=algo), want), (S.size, k, "one pass")
+    monkeypatch.delenv("KISS_HIP_INDUCE_ONE_PASS", raising=False)
+
+
 def test_kernel_class_timing_can_be_limited_to_chosen_classes(oracle):
     # kiss_hip_ctx_set_profiling_mask: HIP events only around the launches of the named classes (what bench.py does for the
     # dominant kernel inside its timed region); the result does not depend on what is timed
@@ -429,6 +447,82 @@ def test_two_contexts_concurrently(oracle):
         t.start()
     for t in th:
         t.join()
+    assert not errors, errors
+
+
+def test_one_shot_calls_reuse_a_cached_context(oracle):
+    # kiss_hip_suffix_sort_dna_u32 (what the C++ facade binds) keeps one context per device between calls: grown for a longer
+    # text, reused for a shorter one, given back by kiss_hip_release_cached_contexts; same results as a context of one's own
+    import torch
+    import kiss_amd
+    from kiss_amd import _lib
+    lib = _lib.load()
+    lib.kiss_hip_release_cached_contexts.restype = int
+    assert lib.kiss_hip_release_cached_contexts() == 0
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for n, k in ((200_000, 256), (1_500_000, 256), (300_000, kiss_amd.K_UNBOUNDED), (1_500_000, 32)):
+        S = gen.genome_like(n, 7 + n % 13)
+        sorter = kiss_amd.KISS2Sorter if k == kiss_amd.K_UNBOUNDED else kiss_amd.KISS1Sorter
+        assert np.array_equal(sorter.get_suffix_array_dna(S, k), oracle.suffix_sort(S, k)), (n, k)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held > 20 * 1_500_000  # the context of the longest text is still there ...
+    assert lib.kiss_hip_release_cached_contexts() == 0
+    assert free0 - torch.cuda.mem_get_info(0)[0] < held // 4  # ... and gone now
+
+
+def test_sort_beside_verification_and_queries_on_another_context(oracle):
+    # what include/kiss_hip.h promises about contexts used from different host threads, one deterministic run per claim:
+    # while thread A sorts (k = 256, then exact order) thread B, on its own context, verifies a finished suffix array on the
+    # device and runs FM queries.  Everything against the oracle.
+    import threading
+    import torch
+    import kiss_amd
+    import kiss_amd.fm_index as fm
+    dev = torch.device("cuda", 0)
+    S = gen.genome_like(400_000, 11)
+    T = gen.genome_like(300_000, 5)
+    want256, want_exact = oracle.suffix_sort(S, 256), oracle.suffix_sort(S, kiss_amd.K_UNBOUNDED)
+    sa_T = oracle.suffix_sort(T, 256)
+    f = fm.FMIndex().build(T)
+    ref = oracle.fm_build(T, oracle.suffix_sort(T, 32))
+    rng = np.random.default_rng(3)
+    pats = np.stack([T[p:p + 24] for p in rng.integers(0, T.size - 24, 5000)]).astype(np.uint8)
+    want_q = ref.query_batch(pats)
+    errors = []
+
+    def sorter():
+        try:
+            with kiss_amd.Context(max_n=S.size) as c:
+                for _ in range(6):
+                    if not np.array_equal(c.suffix_sort(S, 256), want256):
+                        errors.append("k = 256 differs")
+                    if not np.array_equal(c.suffix_sort(S, kiss_amd.K_UNBOUNDED, algo=1), want_exact):
+                        errors.append("exact order differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def checker():
+        try:
+            with kiss_amd.Context(max_n=T.size) as c:
+                d_T = torch.from_numpy(T).to(dev)
+                d_SA = torch.from_numpy(sa_T.view(np.int32)).to(dev)
+                for _ in range(12):
+                    rep = c.verify_sa_dev(d_T.data_ptr(), T.size, d_SA.data_ptr(), 256)
+                    if not rep["ok"]:
+                        errors.append("verification of a correct SA failed: %r" % (rep,))
+                    got = f.query_batch(pats)
+                    if not (np.array_equal(got["beg"], want_q["beg"]) and np.array_equal(got["end"], want_q["end"])
+                            and got["checksum"] == want_q["checksum"] and np.array_equal(got["offsets"], want_q["offsets"])):
+                        errors.append("FM queries differ")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=sorter), threading.Thread(target=checker)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    f.close()
     assert not errors, errors
 
 
