@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define KISS_HIP_VERSION 102 /* 0.1.2: refine_form in kiss_hip_stats (the former reserved word), kiss_hip_stage_induce_exact */
+#define KISS_HIP_VERSION 103 /* 0.1.3: kiss_hip_get_stats_sized, kiss_hip_has_hooks, kiss_hip_release_cached_contexts; from here on
+                              * kiss_hip_stats only ever grows at its END (0.1.2 put three fields in the middle: callers built
+                              * against 0.1.0 must be rebuilt) */
 
 typedef enum kiss_hip_status {
     KISS_HIP_OK = 0,
@@ -96,6 +98,10 @@ typedef struct kiss_hip_stats {
     /* kiss_hip_fmi_query_batch_dev with KISS_HIP_K_FM_QUERY timed: the two halves of ms_kernel[KISS_HIP_K_FM_QUERY] */
     float ms_fm_range;        /* backward search (get_range) */
     float ms_fm_locate;       /* get_offsets */
+    /* appended in 0.1.3 (fields are only ever appended from here on) */
+    uint32_t tie_run_retries; /* near-end placement: searches of the tie runs that failed their verification and were
+                               * repeated (0 on an undisturbed device; see DESIGN.md 4.2 when it is not) */
+    uint32_t reserved_tail_;
 } kiss_hip_stats;
 
 /* kernel classes for ms_kernel[] / launches_kernel[] */
@@ -144,6 +150,9 @@ int kiss_hip_ctx_set_profiling_mask(kiss_hip_ctx *ctx, uint64_t class_mask);
 /* last hipError_t seen by this ctx (0 = hipSuccess) and its string */
 int kiss_hip_last_hip_error(const kiss_hip_ctx *ctx, const char **msg);
 int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out);
+/* the same for a caller built against an older (shorter) or newer (longer) kiss_hip_stats: copies min(bytes, sizeof the
+ * library's struct) bytes and zero-fills the rest of the caller's -- fields are only appended (see KISS_HIP_VERSION) */
+int kiss_hip_get_stats_sized(const kiss_hip_ctx *ctx, void *out, uint64_t bytes);
 /* bytes of device workspace the ctx holds */
 int kiss_hip_ctx_workspace_bytes(const kiss_hip_ctx *ctx, uint64_t *bytes);
 /* the host-pointer entry points keep device-side copies of the caller's buffers between calls (5 bytes per base of

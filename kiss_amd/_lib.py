@@ -42,6 +42,7 @@ class Stats(ctypes.Structure):
         ("refine_items", ctypes.c_uint64), ("refine_depth", ctypes.c_uint32), ("doubling_rounds", ctypes.c_uint32),
         ("ms_refine", ctypes.c_float), ("ms_h2d", ctypes.c_float), ("ms_d2h", ctypes.c_float),
         ("refine_form", ctypes.c_uint32), ("ms_fm_range", ctypes.c_float), ("ms_fm_locate", ctypes.c_float),
+        ("tie_run_retries", ctypes.c_uint32), ("reserved_tail_", ctypes.c_uint32),
     ]
 
     def as_dict(self):
@@ -119,7 +120,7 @@ def load(hooks=None):
     lib = ctypes.CDLL(path)
     if hasattr(lib, "kiss_hip_has_hooks"):  # (a variant named by KISS_AMD_LIB_PATH may be a build of an earlier round)
         lib.kiss_hip_has_hooks.restype = ctypes.c_int
-        if bool(lib.kiss_hip_has_hooks()) != hooks:
+        if bool(lib.kiss_hip_has_hooks()) != hooks and not os.environ.get("KISS_AMD_LIB_PATH"):
             raise ImportError("%s is not the %s build" % (path, "hooks" if hooks else "default"))
     elif hooks:
         raise ImportError("%s is not a hooks build" % path)
@@ -232,5 +233,5 @@ EXPORTED_SYMBOLS = [
     "kiss_hip_multi_create", "kiss_hip_multi_destroy", "kiss_hip_multi_suffix_sort_dna_u32",
     "kiss_hip_multi_suffix_sort_dna_u32_dev", "kiss_hip_multi_get_stats", "kiss_hip_multi_ctx",
     "kiss_hip_suffix_sort_dna_u32_multi", "kiss_hip_debug_splitters", "kiss_hip_debug_fail_alloc_over",
-    "kiss_hip_has_hooks", "kiss_hip_release_cached_contexts",
+    "kiss_hip_has_hooks", "kiss_hip_release_cached_contexts", "kiss_hip_get_stats_sized",
 ]

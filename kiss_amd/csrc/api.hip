@@ -66,10 +66,8 @@ void kiss_opts_refresh(kiss_hip_ctx *ctx)
     o.no_pivot_rounds = env_on("KISS_HIP_NO_PIVOT_ROUNDS");
     o.pivot_from_round2 = env_on("KISS_HIP_PIVOT_FROM_ROUND2");
     o.pair_keys = env_on("KISS_HIP_PAIR_KEYS");
-    o.no_pair_diag = env_on("KISS_HIP_NO_PAIR_DIAG");
     o.no_fc0_onepass = env_on("KISS_HIP_NO_FC0_ONEPASS");
     o.no_pivot_ctx = env_on("KISS_HIP_NO_PIVOT_CTX");
-    o.fc0_form = (int)env_u64("KISS_HIP_FC0_FORM", 2);
     o.no_taint = env_on("KISS_HIP_NO_TAINT");
     o.isa_direct = env_on("KISS_HIP_ISA_DIRECT");
     o.no_onesweep = env_on("KISS_HIP_NO_ONESWEEP");
@@ -467,7 +465,7 @@ int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)
         ctx->rx_tiles_cap = m_cap / 16384 + 2;
         ALLOC(rx_desc, 256 * ctx->rx_tiles_cap);
         ALLOC(rx_ghist, 256 * 12);
-        ctx->fc_desc_cap = m_cap / 2048 + 4; // (room for the 2048-item tiles of the smallest one-pass form)
+        ctx->fc_desc_cap = m_cap / 8192 + 4;
         ALLOC(fc_desc, ctx->fc_desc_cap);
 #undef ALLOC
         // descriptors carry the epoch of the pass that wrote them: cleared once, never again (the epoch keeps counting)
@@ -767,6 +765,15 @@ int kiss_hip_get_stats(const kiss_hip_ctx *ctx, kiss_hip_stats *out)
 {
     if (!ctx || !out) return KISS_HIP_E_INVALID;
     *out = ctx->stats;
+    return KISS_HIP_OK;
+}
+
+int kiss_hip_get_stats_sized(const kiss_hip_ctx *ctx, void *out, uint64_t bytes)
+{
+    if (!ctx || !out) return KISS_HIP_E_INVALID;
+    const uint64_t have = sizeof ctx->stats;
+    std::memcpy(out, &ctx->stats, bytes < have ? bytes : have);
+    if (bytes > have) std::memset(static_cast<char *>(out) + have, 0, bytes - have);
     return KISS_HIP_OK;
 }
 

@@ -58,8 +58,8 @@ struct WordMasks {
 __device__ __forceinline__ WordMasks word_masks(const uint64_t *__restrict__ pk, uint64_t w, uint64_t n)
 {
     WordMasks m;
-    uint64_t x = pk[w];
-    uint64_t nx = pk[w + 1];
+    uint64_t x, nx;
+    kiss_words2(pk, w, x, nx); // (aligned loads: kiss_internal.hpp)
     uint64_t y = (x << 2) | (nx >> 62); // field j of y = base 32w+j+1
     uint64_t d = x ^ y;
     uint64_t eqh = ~d & HI;

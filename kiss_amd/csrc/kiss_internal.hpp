@@ -25,10 +25,8 @@ struct KissOpts {
     bool no_early_out = false;     // KISS_HIP_NO_EARLY_OUT
     bool no_pivot_rounds = false;  // KISS_HIP_NO_PIVOT_ROUNDS: 32-base rounds only
     bool pivot_from_round2 = false;// KISS_HIP_PIVOT_FROM_ROUND2
-    bool no_pair_diag = false;     // KISS_HIP_NO_PAIR_DIAG: tied pairs of the first refinement round by one walk each (round 3)
     bool pair_keys = false;        // KISS_HIP_PAIR_KEYS: gather the round's key for pairs as well
     bool no_fc0_onepass = false;   // KISS_HIP_NO_FC0_ONEPASS: count + scan + compact after round 0
-    int fc0_form = 2;              // KISS_HIP_FC0_FORM: 1 = the one-pass kernel of round 3 (88 VGPRs), 2 = the two-per-CU form
     bool no_pivot_ctx = false;     // KISS_HIP_NO_PIVOT_CTX
     bool no_taint = false;         // KISS_HIP_NO_TAINT: the suffix-array form compares every neighbour pair
     bool isa_direct = false;       // KISS_HIP_ISA_DIRECT: inverse SA by plain random scatter
@@ -329,14 +327,42 @@ int kiss_early_out(kiss_hip_ctx *ctx, const uint32_t *d_SA, uint64_t lo, uint64_
 
 // ---- device helpers ----------------------------------------------------------------
 #ifdef __HIPCC__
-// 32 bases starting at base index p (zero = 'A' padding past the end; pk has >= 2 spare zero words)
+// ---- loads from the packed text: NATURALLY ALIGNED, always (round 4) -------------------------------------
+// A key of 32 bases at an arbitrary position needs two consecutive words; written as one 16-byte load at an 8-byte aligned
+// address (rounds 1-3; hipcc also merges `pk[w], pk[w + 1]` into exactly that) the compare loop of k_near_tie_runs returned
+// wrong answers for a whole wave whenever another stream kept the memory system busy -- 17.6 % of the launches of
+// tools/repro/near_tie_runs_glitch.hip, none with the loads below (same kernel, same noise).  The rule of this code base since:
+// a vector load of the packed text starts at a multiple of its own size.  Two words = the 16-byte aligned pair that holds word
+// w + the word behind that pair (24 bytes instead of 16; pk carries >= 7 spare zero words behind the text).
+__device__ __forceinline__ void kiss_words2(const uint64_t *__restrict__ pk, uint64_t w, uint64_t &a, uint64_t &b)
+{
+    const uint64_t w0 = w & ~1ull;
+    const ulonglong2 ab = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(pk + w0, 16));
+    const uint64_t c = pk[w0 + 2];
+    const bool odd = (w & 1ull) != 0;
+    a = odd ? ab.y : ab.x;
+    b = odd ? c : ab.y;
+}
+// five consecutive words from word w on (four 32-base keys at any base offset): three aligned 16-byte loads
+__device__ __forceinline__ void kiss_words5(const uint64_t *__restrict__ pk, uint64_t w, uint64_t x[5])
+{
+    const uint64_t w0 = w & ~1ull;
+    const ulonglong2 p0 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(pk + w0, 16));
+    const ulonglong2 p1 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(pk + w0 + 2, 16));
+    const ulonglong2 p2 = *reinterpret_cast<const ulonglong2 *>(__builtin_assume_aligned(pk + w0 + 4, 16));
+    const bool odd = (w & 1ull) != 0;
+    x[0] = odd ? p0.y : p0.x;
+    x[1] = odd ? p1.x : p0.y;
+    x[2] = odd ? p1.y : p1.x;
+    x[3] = odd ? p2.x : p1.y;
+    x[4] = odd ? p2.y : p2.x;
+}
+// 32 bases starting at base index p (zero = 'A' padding past the end)
 __device__ __forceinline__ uint64_t kiss_key32(const uint64_t *__restrict__ pk, uint64_t p)
 {
-    uint64_t w = p >> 5;
-    uint32_t s = (uint32_t)(p & 31u) * 2u;
-    // one 16-byte load for both words (global loads only need dword alignment on gfx950)
-    const ulonglong2 ab = *reinterpret_cast<const ulonglong2 *>(pk + w);
-    const uint64_t a = ab.x, b = ab.y;
+    const uint32_t s = (uint32_t)(p & 31u) * 2u;
+    uint64_t a, b;
+    kiss_words2(pk, p >> 5, a, b);
     return (a << s) | ((b >> 1) >> (63u - s)); // branch-free: s == 0 gives a
 }
 __device__ __forceinline__ uint32_t kiss_base(const uint64_t *__restrict__ pk, uint64_t p)

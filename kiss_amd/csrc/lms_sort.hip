@@ -79,14 +79,10 @@ __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint6
         if (qi + 96 < n && qj + 96 < n && (!depth || depth - d >= 128)) {
             // 128 bases per step: the ten word loads are independent, so one round trip to memory covers four
             // 32-base compares (the walk through a long repeat is a chain of dependent loads otherwise)
-            const uint64_t *wi = pk + (qi >> 5), *wj = pk + (qj >> 5);
             const uint32_t si = 2u * (uint32_t)(qi & 31u), sj = 2u * (uint32_t)(qj & 31u);
             uint64_t a[5], b[5];
-#pragma unroll
-            for (int t = 0; t < 5; t++) {
-                a[t] = wi[t];
-                b[t] = wj[t];
-            }
+            kiss_words5(pk, qi >> 5, a); // (aligned loads: kiss_internal.hpp)
+            kiss_words5(pk, qj >> 5, b);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));
@@ -101,14 +97,10 @@ __device__ __forceinline__ bool deep_less(const uint64_t *__restrict__ pk, uint6
             // dependent 32-base steps.  It overlaps bases already found equal, which changes nothing: the first
             // differing word still holds the first differing base.
             const uint64_t ri = pi + depth - 128, rj = pj + depth - 128;
-            const uint64_t *wi = pk + (ri >> 5), *wj = pk + (rj >> 5);
             const uint32_t si = 2u * (uint32_t)(ri & 31u), sj = 2u * (uint32_t)(rj & 31u);
             uint64_t a[5], b[5];
-#pragma unroll
-            for (int t = 0; t < 5; t++) {
-                a[t] = wi[t];
-                b[t] = wj[t];
-            }
+            kiss_words5(pk, ri >> 5, a);
+            kiss_words5(pk, rj >> 5, b);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));
@@ -160,124 +152,6 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_adjacent(const uint64_t *__r
     inorder[i] = ok;
 }
 
-// ---- pairs along their diagonals (round 4) -------------------------------------------------------------------------
-// By far the most common tied segment after round 0 is a PAIR: two copies of a duplicated stretch.  k_seg_finish walks
-// every pair from base 20 to the depth D (three dependent 128-base steps over two random places of the text: ~45 M walks,
-// 400 M random sector reads, 9 ms at chm13 size).  But the pairs of one duplicated stretch lie on one DIAGONAL (position of
-// the second copy - position of the first), a few bases apart, and their walks read the same bases over and over: the
-// first mismatch of the pair at position p is the first mismatch of the diagonal at or after p + 20.  So:
-//   k_pair_keys : one record per tied segment, key = (position of the first copy << 32 | diagonal), ~0 for non-pairs
-//   radix sort on the position half (4 passes of 12-byte records; the diagonal rides in the unsorted half)
-//   k_pair_diag : consecutive records on the same diagonal form a run; a record compares the text only over the gap to the
-//                 next record of its run (the last one to the depth) and learns the first mismatch at or after its own
-//                 start from the records after it (at most D / 2 of them: LMS positions are >= 2 apart) -- one byte per
-//                 pair goes back to the pair's place: 1 | 2 (the first copy is smaller) | 4 (equal through the depth)
-// and k_seg_finish reads the byte instead of walking.  Same comparator (kiss1_core.hpp:94-135): first difference in
-// bases [20, D) decides, none -> the smaller position first, tainted.
-constexpr int PD_THREADS = 256;
-// records behind a tile that a record of the tile may need: the records of its run that start inside its depth, at most
-// (D - 20) / 2 of them (LMS positions are at least 2 apart) -- D <= 660 (k <= 624: the default 256 and the 512 of the exact
-// order's bounded phase); a deeper order keeps the walk of k_seg_finish
-constexpr int PD_HALO = 320;
-constexpr int PD_TILE = 8 * PD_THREADS - PD_HALO; // records a workgroup decides; it loads PD_TILE + PD_HALO = 2048
-
-__global__ __launch_bounds__(LS_THREADS) void k_pair_keys(const uint32_t *__restrict__ pos,
-                                                         const uint32_t *__restrict__ segstart, uint64_t nseg,
-                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ first)
-{
-    const uint64_t sg = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (sg >= nseg) return;
-    const uint32_t a = segstart[sg], b = segstart[sg + 1];
-    uint64_t k = ~0ull;
-    if (b - a == 2) {
-        const uint32_t pa = pos[a], pb = pos[a + 1]; // (position order inside a segment: pa < pb)
-        k = ((uint64_t)pa << 32) | (uint64_t)(pb - pa);
-    }
-    key[sg] = k;
-    first[sg] = a;
-}
-
-// first x in [x0, x1) with base(x) != base(x + dg), or ~0ull; *a_less = base(x) < base(x + dg)
-__device__ __forceinline__ uint64_t diag_mismatch(const uint64_t *__restrict__ pk, uint64_t x0, uint64_t x1, uint64_t dg,
-                                                  bool *a_less)
-{
-    uint64_t x = x0;
-    while (x < x1) {
-        const uint64_t ka = kiss_key32(pk, x), kb = kiss_key32(pk, x + dg);
-        const uint64_t diff = ka ^ kb;
-        if (diff) {
-            const uint64_t m = x + (uint64_t)(__builtin_clzll(diff) >> 1);
-            if (m >= x1) return ~0ull;
-            *a_less = ka < kb; // (the first differing base decides the 64-bit compare)
-            return m;
-        }
-        x += 32;
-    }
-    return ~0ull;
-}
-
-__global__ __launch_bounds__(PD_THREADS) void k_pair_diag(const uint64_t *__restrict__ pk, const uint64_t *__restrict__ key,
-                                                         const uint32_t *__restrict__ first, uint64_t nrec, uint64_t off,
-                                                         uint64_t depth, uint8_t *__restrict__ res)
-{
-    __shared__ uint32_t s_pa[PD_TILE + PD_HALO + 1]; // position of the first copy (0xFFFFFFFF: not a pair / past the end)
-    __shared__ uint32_t s_dg[PD_TILE + PD_HALO + 1];
-    __shared__ uint32_t s_mm[PD_TILE + PD_HALO];     // first mismatch found in the record's own stretch, 0xFFFFFFFF = none
-    __shared__ uint8_t s_less[PD_TILE + PD_HALO];
-    const uint64_t base = (uint64_t)blockIdx.x * PD_TILE;
-    for (uint32_t l = threadIdx.x; l < PD_TILE + PD_HALO + 1; l += PD_THREADS) {
-        const uint64_t j = base + l;
-        const uint64_t k = j < nrec ? key[j] : ~0ull;
-        s_pa[l] = (uint32_t)(k >> 32);
-        s_dg[l] = (uint32_t)k;
-    }
-    __syncthreads();
-    // every record: its own stretch [pa + off, next record of the run + off), the last of a run [pa + off, pa + depth)
-    for (uint32_t l = threadIdx.x; l < PD_TILE + PD_HALO; l += PD_THREADS) {
-        const uint32_t pa = s_pa[l], dg = s_dg[l];
-        uint32_t mm = 0xFFFFFFFFu;
-        bool less = false;
-        if (!(pa == 0xFFFFFFFFu && dg == 0xFFFFFFFFu)) {
-            const uint32_t pn = s_pa[l + 1];
-            const bool chained = s_dg[l + 1] == dg && pn != 0xFFFFFFFFu && pn > pa && (uint64_t)pn - pa < depth - off;
-            const uint64_t x0 = (uint64_t)pa + off, x1 = chained ? (uint64_t)pn + off : (uint64_t)pa + depth;
-            const uint64_t m = diag_mismatch(pk, x0, x1, dg, &less);
-            if (m != ~0ull) mm = (uint32_t)m;
-        }
-        s_mm[l] = mm;
-        s_less[l] = less ? 1 : 0;
-    }
-    __syncthreads();
-    // the first mismatch at or after my start: mine, or that of a later record of my run, as long as it lies inside my depth
-    for (uint32_t l = threadIdx.x; l < PD_TILE; l += PD_THREADS) {
-        const uint64_t j = base + l;
-        if (j >= nrec) break;
-        const uint32_t pa = s_pa[l], dg = s_dg[l];
-        if (pa == 0xFFFFFFFFu && dg == 0xFFFFFFFFu) continue; // not a pair (sorted behind all pairs)
-        const uint64_t end = (uint64_t)pa + depth; // bases [pa + off, pa + depth) count
-        uint8_t r = 1 | 4; // tied through the depth unless a mismatch turns up
-        uint32_t t = l;
-        for (;;) {
-            const uint32_t mm = s_mm[t];
-            if (mm != 0xFFFFFFFFu) {
-                if ((uint64_t)mm < end) r = (uint8_t)(1 | (s_less[t] ? 2 : 0));
-                break;
-            }
-            // no mismatch in record t's stretch: does the run go on (and still inside my depth)?
-            const uint32_t pn = s_pa[t + 1];
-            const bool chained = s_dg[t + 1] == dg && pn != 0xFFFFFFFFu && pn > s_pa[t] && (uint64_t)pn - s_pa[t] < depth - off;
-            if (!chained) break;                          // record t walked to its own depth >= mine: tied
-            if ((uint64_t)pn + off >= end) break;         // the next stretch starts past my depth: tied
-            t++;
-            if (t >= PD_TILE + PD_HALO) {                 // (cannot happen: at most (depth - off) / 2 records ahead; see the host check)
-                r = 0;
-                break;
-            }
-        }
-        res[first[j]] = r;
-    }
-}
-
 // small segments: final rank of every member, written straight to its final slot;
 // big segments: flagged for the radix path.  big[i] = (1 << 32) | (first item of a big segment)
 __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__restrict__ pk, uint64_t n,
@@ -292,10 +166,8 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           uint32_t *__restrict__ nbig,
                                                           const uint32_t *__restrict__ tctx, // first round only: the
                                                           uint32_t *__restrict__ octx,       // items' context words
-                                                          uint8_t *__restrict__ hfar, // optional: 0 for an item that retires
+                                                          uint8_t *__restrict__ hfar) // optional: 0 for an item that retires
                                                           // tied with the one before it in the final order (ctx->hfar)
-                                                          const uint8_t *__restrict__ pres) // optional: pres[first member of a
-                                                          // pair] = what k_pair_diag found (0: nothing, walk)
 {
     const uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
     const bool valid = i < count;
@@ -320,13 +192,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
         if (!second_in_wave && b - a == 2) {
             // a pair: no keys were gathered for it (k_gather_keys); one walk from the segment's depth decides
             const uint32_t j = (uint32_t)i == a ? a + 1 : a;
-            const uint8_t pr = pres ? pres[a] : (uint8_t)0;
-            if (pr) { // decided along the diagonal (k_pair_diag): bit 1 = the first copy is smaller, bit 2 = tied through the depth
-                taint = (pr & 4) != 0;
-                const bool first_smaller = (pr & 6) != 0; // (a tie goes to the smaller position = the first copy)
-                r = ((uint32_t)i == a) ? (first_smaller ? 0u : 1u) : (first_smaller ? 1u : 0u);
-            } else
-                r = deep_less(pk, n, pos[j], pi, off - 32, depth, j < (uint32_t)i, &taint) ? 1u : 0u;
+            r = deep_less(pk, n, pos[j], pi, off - 32, depth, j < (uint32_t)i, &taint) ? 1u : 0u;
         } else if (!second_in_wave) {
             const uint64_t ki = key[i];
             bool sorted = false;
@@ -508,11 +374,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_big_writeback(const uint64_t *__
 // four aligned 32-base keys starting at base q (five independent word loads)
 __device__ __forceinline__ void keys128(const uint64_t *__restrict__ pk, uint64_t q, uint64_t k[4])
 {
-    const uint64_t *w = pk + (q >> 5);
     const uint32_t sh = 2u * (uint32_t)(q & 31u);
     uint64_t x[5];
-#pragma unroll
-    for (int t = 0; t < 5; t++) x[t] = w[t];
+    kiss_words5(pk, q >> 5, x);
 #pragma unroll
     for (int t = 0; t < 4; t++) k[t] = (x[t] << sh) | ((x[t + 1] >> 1) >> (63u - sh));
 }
@@ -1104,186 +968,6 @@ __global__ __launch_bounds__(FC1_THREADS) void k_fc0_onepass(const uint64_t *__r
     }
 }
 
-// ---- the same pass with half the registers (round 4) -----------------------------------------------------------------
-// k_fc0_onepass needs 88 VGPRs: with 16 waves per workgroup ONE workgroup fits a CU, and a tile is a chain of latencies
-// (ticket, key loads, look-back, stores: 13 us for 160 KB).  This form keeps the raw keys only (the payload bits are their
-// low 24 bits, the compared bits the rest), reads a position only for the items that survive (18 % on genome-like text:
-// the other positions are where they belong already) and after the look-back: <= 64 VGPRs, two workgroups per CU, two tiles
-// in flight per CU.
-template <int THREADS, int MIN_WAVES_PER_EU>
-__global__ __launch_bounds__(THREADS, MIN_WAVES_PER_EU) void k_fc0_onepass2(const uint64_t *__restrict__ key,
-                                                                const uint32_t *__restrict__ pos, uint64_t count,
-                                                                int cmp_shift, uint64_t tiles, uint64_t *__restrict__ desc,
-                                                                uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
-                                                                uint32_t *__restrict__ npos, uint32_t *__restrict__ nslot,
-                                                                uint32_t *__restrict__ nseg, uint32_t *__restrict__ nsegstart,
-                                                                uint32_t *__restrict__ octx, uint32_t *__restrict__ nctx,
-                                                                uint64_t cap, uint64_t *__restrict__ total)
-{
-    __shared__ uint32_t ws[THREADS / 64][2];
-    __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_excl[2];
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint64_t tile = s_tile;
-    if (tile >= tiles) return;
-    const int wave = threadIdx.x >> 6;
-    const uint32_t lane = lane_id();
-    const uint64_t i0 = (tile * THREADS + threadIdx.x) * FC_ITEMS;
-    // kk[0] = key before my first item, kk[1 .. FC_ITEMS] = my items, kk[FC_ITEMS + 1] = key after (raw)
-    uint64_t kk[FC_ITEMS + 2];
-    const uint32_t valid = i0 >= count ? 0u : (count - i0 >= FC_ITEMS ? (uint32_t)FC_ITEMS : (uint32_t)(count - i0));
-    if (valid == FC_ITEMS) {
-#pragma unroll
-        for (int q = 0; q < FC_ITEMS / 2; q++) {
-            const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(key + i0 + 2 * q);
-            kk[1 + 2 * q] = t.x;
-            kk[2 + 2 * q] = t.y;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++) kk[1 + e] = (uint32_t)e < valid ? key[i0 + e] : 0ull;
-    }
-    kk[0] = (valid && i0 > 0) ? key[i0 - 1] : 0ull;
-    kk[FC_ITEMS + 1] = (valid && i0 + FC_ITEMS < count) ? key[i0 + FC_ITEMS] : 0ull;
-    uint32_t sm = 0, hm = 0;
-#pragma unroll
-    for (int e = 0; e < FC_ITEMS; e++) {
-        if ((uint32_t)e < valid) {
-            const uint64_t i = i0 + (uint64_t)e;
-            const bool head = i == 0 || ((kk[e] ^ kk[e + 1]) >> cmp_shift) != 0;
-            const bool nhead = i + 1 == count || ((kk[e + 2] ^ kk[e + 1]) >> cmp_shift) != 0;
-            const bool surv = !(head && nhead);
-            sm |= (surv ? 1u : 0u) << e;
-            hm |= ((surv && head) ? 1u : 0u) << e;
-        }
-    }
-    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
-    uint32_t is = ns, ih = nh; // inclusive wave prefixes
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
-        if ((int)lane >= d) {
-            is += os;
-            ih += oh;
-        }
-    }
-    if (lane == 63) {
-        ws[wave][0] = is;
-        ws[wave][1] = ih;
-    }
-    __syncthreads();
-    uint32_t ts = 0, th = 0, ws0 = 0, wh0 = 0; // tile totals; totals of the waves before mine
-#pragma unroll
-    for (int w = 0; w < THREADS / 64; w++) {
-        if (w < wave) {
-            ws0 += ws[w][0];
-            wh0 += ws[w][1];
-        }
-        ts += ws[w][0];
-        th += ws[w][1];
-    }
-    if (wave == 0) {
-        constexpr uint64_t M31 = 0x7FFFFFFFull;
-        const uint64_t mine = ((uint64_t)ts << 31) | (uint64_t)th;
-        uint64_t es = 0, eh = 0; // survivors / heads in all earlier tiles
-        if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(&desc[0], (2ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(&desc[tile], (1ull << 62) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // The look-back inspects LB = 4 descriptors per lane = 256 predecessors per round trip.  Tiles cannot publish
-            // running totals faster than (window x tile) items per round trip (every tile started within the last look-back
-            // latency is still without one), and with two workgroups per CU twice as many tiles are in flight: 64 x 8192
-            // items per 1.5 us would cap this pass at 2.6 ms by itself.
-            constexpr int LB = 4;
-            int64_t base = (int64_t)tile;
-            uint32_t spins = 0;
-            for (;;) {
-                uint64_t v[LB];
-                uint32_t incl_m = 0, ready_m = 0; // bit q: descriptor q of this lane carries a running total / is published
-#pragma unroll
-                for (int q = 0; q < LB; q++) {
-                    const int64_t t = base - 1 - (int64_t)(LB * lane + q); // lane 0 holds the nearest predecessors
-                    v[q] = t >= 0 ? __hip_atomic_load(&desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-                    const uint32_t st = (uint32_t)(v[q] >> 62);
-                    incl_m |= (st == 2u ? 1u : 0u) << q;
-                    ready_m |= (st != 0u ? 1u : 0u) << q;
-                }
-                // nearest running total: lowest (lane, q); everything nearer must be published
-                const uint64_t lanes_incl = __ballot(incl_m != 0u);
-                const uint32_t fl = lanes_incl ? (uint32_t)__builtin_ctzll(lanes_incl) : 64u; // lane holding it
-                const uint32_t fq = (uint32_t)__shfl((int)(incl_m ? (uint32_t)__builtin_ctz(incl_m) : (uint32_t)LB), (int)(fl & 63u), 64);
-                // lanes < fl need all LB published; lane fl needs descriptors 0 .. fq
-                const uint32_t need_m = lane < fl ? (1u << LB) - 1u : (lane == fl ? (2u << fq) - 1u : 0u);
-                if (__ballot((ready_m & need_m) != need_m)) { // a predecessor this side of it has not published yet
-                    if (++spins > FC1_SPIN_LIMIT) {
-                        if (lane == 0) *err = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                uint64_t a = 0, b2 = 0;
-#pragma unroll
-                for (int q = 0; q < LB; q++)
-                    if ((need_m >> q) & 1u) {
-                        a += (v[q] >> 31) & M31;
-                        b2 += v[q] & M31;
-                    }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    a += __shfl_xor(a, d, 64);
-                    b2 += __shfl_xor(b2, d, 64);
-                }
-                es += a;
-                eh += b2;
-                if (fl < 64u) break;
-                base -= 64 * LB;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&desc[tile], (2ull << 62) | ((es + ts) << 31) | (eh + th), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            s_excl[0] = (uint32_t)es;
-            s_excl[1] = (uint32_t)eh;
-            if (tile + 1 == tiles) total[0] = ((es + ts) << 32) | (eh + th);
-        }
-    }
-    __syncthreads();
-    if (valid == 0) return;
-    uint32_t bs = s_excl[0] + ws0 + (is - ns), bh = s_excl[1] + wh0 + (ih - nh);
-#pragma unroll
-    for (int e = 0; e < FC_ITEMS; e++) {
-        if ((sm >> e) & 1u) {
-            const uint32_t ni = bs++;
-            if ((hm >> e) & 1u) bh++;
-            const uint32_t sid = bh - 1u; // heads up to and including this item's own segment head
-            if (ni < cap) {
-                npos[ni] = pos[i0 + e]; // (only a tied item's position is read here: the others stay where the sort wrote them)
-                nslot[ni] = (uint32_t)(i0 + e);
-                nseg[ni] = sid;
-                if ((hm >> e) & 1u) nsegstart[sid] = ni;
-                if (nctx) nctx[ni] = (uint32_t)(kk[e + 1] & KISS_KEY_CTX_MASK); // travels with the tied item through the first refinement round
-            }
-        }
-    }
-    // context words: the payload of the key; 0 for a tied item (written when it is finished, else gathered at placement)
-    if (valid == FC_ITEMS) {
-#pragma unroll
-        for (int q = 0; q < FC_ITEMS / 4; q++) {
-            uint32_t w[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) w[e] = ((sm >> (4 * q + e)) & 1u) ? 0u : (uint32_t)(kk[4 * q + e + 1] & KISS_KEY_CTX_MASK);
-            *reinterpret_cast<uint4 *>(octx + i0 + 4 * q) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++)
-            if ((uint32_t)e < valid) octx[i0 + e] = ((sm >> e) & 1u) ? 0u : (uint32_t)(kk[e + 1] & KISS_KEY_CTX_MASK);
-    }
-}
-
 // ---- tie flags as bytes (the doubling phase's first compaction over all n + 1 suffixes): 8 flags per load, and the
 // suffix array is read only for the few entries that are tied ------------------------------------------------
 __device__ __forceinline__ void fch_flags(const uint8_t *__restrict__ hb, uint64_t i0, uint64_t count, uint32_t &valid,
@@ -1557,9 +1241,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
     uint64_t tot;
     bool have_tctx = false; // bslot is free until the big-segment path of the first round: the tied items' context words
     const bool no_onepass = ctx->opts.no_fc0_onepass;
-    // (hooks build: forms 3 / 4 of the one-pass kernel work on 4096- / 2048-item tiles)
-    const uint64_t fc1_tile = ctx->opts.fc0_form == 3 ? 512 * FC_ITEMS : (ctx->opts.fc0_form == 4 ? 256 * FC_ITEMS : FC1_TILE);
-    const uint64_t tiles1 = div_up(count, fc1_tile);
+    const uint64_t tiles1 = div_up(count, FC1_TILE);
     // (the result of the five passes is in buffer 1 = the output list itself, so there are no positions to copy)
     const bool onepass = !no_onepass && ctx->fc_desc && tiles1 >= 8 && tiles1 + 1 <= ctx->fc_desc_cap &&
                          rb.pos[res] == ctx->lms_sorted_far;
@@ -1570,26 +1252,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             KTRY(kiss_zero_u32(ctx, desc, 2 * tiles1 + 2));
             {
                 KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-                if (ctx->opts.fc0_form == 1) // (hooks build: the 88-register form of round 3, one workgroup per CU)
-                    hipLaunchKernelGGL(k_fc0_onepass, dim3((unsigned)tiles1), dim3(FC1_THREADS), 0, ctx->stream, rb.key[res], rb.pos[res],
-                                       count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
-                                       ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
-                else if (ctx->opts.fc0_form == 3)
-                    hipLaunchKernelGGL((k_fc0_onepass2<512, 6>), dim3((unsigned)tiles1), dim3(512), 0, ctx->stream, rb.key[res], rb.pos[res],
-                                       count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
-                                       ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
-                else if (ctx->opts.fc0_form == 4)
-                    hipLaunchKernelGGL((k_fc0_onepass2<256, 6>), dim3((unsigned)tiles1), dim3(256), 0, ctx->stream, rb.key[res], rb.pos[res],
-                                       count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
-                                       ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
-                else if (ctx->opts.fc0_form == 5)
-                    hipLaunchKernelGGL((k_fc0_onepass2<1024, 4>), dim3((unsigned)tiles1), dim3(1024), 0, ctx->stream, rb.key[res], rb.pos[res],
-                                       count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
-                                       ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
-                else
-                    hipLaunchKernelGGL((k_fc0_onepass2<1024, 8>), dim3((unsigned)tiles1), dim3(1024), 0, ctx->stream, rb.key[res], rb.pos[res],
-                                       count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
-                                       ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
+                hipLaunchKernelGGL(k_fc0_onepass, dim3((unsigned)tiles1), dim3(FC1_THREADS), 0, ctx->stream, rb.key[res], rb.pos[res],
+                                   count, r0_shift, tiles1, desc, ticket, ctx->rx_ctl + 1, Pc, ctx->slotA, ctx->segA, ctx->segstartA,
+                                   ctx->lms_ctx_far, ctx->bslot, ctx->t_cap, d_total);
                 KCHECK(hipGetLastError());
             }
             KTRY(fc_read_total(ctx, d_total, &tot));
@@ -1654,34 +1319,11 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, d_nbig);
             uint8_t *inorder = reinterpret_cast<uint8_t *>(F2); // F2 is free until the big-segment scan below
-            // first refinement round, bounded depth: the pairs are decided along their diagonals (k_pair_diag) instead of
-            // by one walk each; scratch: the big-segment arrays (free until k_big_compact of this round) and the bytes of F2
-            // behind `inorder`
-            uint8_t *pres = nullptr;
-            if (first_refine && depth && !ctx->opts.no_pair_diag && nseg >= 2 && depth - off <= 2 * PD_HALO && off == ROUND0_BASES &&
-                nseg <= ctx->t_cap) {
-                pres = inorder + ((count + 15) & ~15ull);
-                hipLaunchKernelGGL(k_pair_keys, dim3((unsigned)div_up(nseg, T)), dim3(T), 0, ctx->stream, Pc, SSc, nseg, ctx->bkeyA,
-                                   ctx->bposA);
-                KCHECK(hipGetLastError());
-                RadixBufs pr;
-                pr.key[0] = ctx->bkeyA;
-                pr.key[1] = ctx->bkeyB;
-                pr.pos[0] = ctx->bposA;
-                pr.pos[1] = ctx->bposB;
-                pr.seg[0] = pr.seg[1] = nullptr;
-                int pres_idx = 0;
-                KTRY(kiss_radix_sort(ctx, pr, nseg, 32, 0, &pres_idx)); // on the position half; the diagonal rides along
-                hipLaunchKernelGGL(k_pair_diag, dim3((unsigned)div_up(nseg, PD_TILE)), dim3(PD_THREADS), 0, ctx->stream, ctx->pk,
-                                   pr.key[pres_idx], pr.pos[pres_idx], nseg, off, depth, pres);
-                KCHECK(hipGetLastError());
-            }
             hipLaunchKernelGGL(k_seg_adjacent, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Gc, SSc, count, off,
                                depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
                                count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig,
-                               (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far, ctx->hfar,
-                               pres);
+                               (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far, ctx->hfar);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
@@ -2367,14 +2009,10 @@ __device__ __forceinline__ bool exact_less(const uint64_t *__restrict__ pk, uint
         const uint64_t qi = pi + d, qj = pj + d;
         const uint64_t ri = n - qi, rj = n - qj; // bases left
         if (ri >= 160 && rj >= 160) {
-            const uint64_t *wi = pk + (qi >> 5), *wj = pk + (qj >> 5);
             const uint32_t si = 2u * (uint32_t)(qi & 31u), sj = 2u * (uint32_t)(qj & 31u);
             uint64_t a[5], b[5];
-#pragma unroll
-            for (int t = 0; t < 5; t++) {
-                a[t] = wi[t];
-                b[t] = wj[t];
-            }
+            kiss_words5(pk, qi >> 5, a); // (aligned loads: kiss_internal.hpp)
+            kiss_words5(pk, qj >> 5, b);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const uint64_t ki = (a[t] << si) | ((a[t + 1] >> 1) >> (63u - si));

@@ -93,9 +93,9 @@ struct SharedDeviceLock {
     std::unique_lock<std::mutex> lk;
     SharedDeviceLock(const kiss_hip_multi *mc, int r)
     {
-        bool shared = false;
-        for (int q = 0; q < mc->G; q++) shared = shared || (q != r && mc->dev[q] == mc->dev[r]);
-        if (shared && !mc->ctx[r]->opts.no_serialize) lk = std::unique_lock<std::mutex>(kiss_device_mutex(mc->dev[r]));
+        // (round 4: always, not only when this device is listed twice -- a plain sort of another context on the same device
+        //  from another thread of the process must not run beside this phase either)
+        if (!mc->ctx[r]->opts.no_serialize) lk = std::unique_lock<std::mutex>(kiss_device_mutex(mc->dev[r]));
     }
 };
 
@@ -308,6 +308,19 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
             rc = sync();
         } else if (!rc) {
             rc = kiss_radix_check(ctx); // (synchronises)
+            // Round 4: the sorted piece LEAVES for device 0 as soon as this rank has it (positions + context words, behind
+            // the pieces of the lower ranks), on this rank's own stream: the G - 1 pieces travel over G - 1 links at once and
+            // under the sorts that are still running, instead of being pulled one after the other by device 0 after the
+            // barrier.  Device 0's own sort works on [0, R[0]) of the same arrays; their capacity was settled before the
+            // exchange (the sort regrows tied-segment arrays only).
+            if (!rc && r > 0 && R[r]) {
+                uint64_t off = 0;
+                for (int g = 0; g < r; g++) off += R[g];
+                kiss_hip_ctx *c0 = mc->ctx[0];
+                rc = copy_between(mc, 0, c0->lms_sorted_far + off, r, ctx->lms_sorted_far, R[r] * sizeof(uint32_t), ctx->stream);
+                if (!rc) rc = copy_between(mc, 0, c0->lms_ctx_far + off, r, ctx->lms_ctx_far, R[r] * sizeof(uint32_t), ctx->stream);
+                if (!rc) rc = sync();
+            }
         }
         fail(rc);
     }
@@ -318,12 +331,7 @@ void rank_attempt(kiss_hip_multi *mc, Shared *sh, int r, clk::time_point *marks)
     if (ok() && r == 0) {
         SharedDeviceLock device_lock(mc, r);
         int rc = KISS_HIP_OK;
-        uint64_t off = R[0];
-        for (int g = 1; g < G && !rc; g++) {
-            rc = copy_between(mc, 0, ctx->lms_sorted_far + off, g, mc->ctx[g]->lms_sorted_far, R[g] * sizeof(uint32_t), ctx->stream);
-            if (!rc) rc = copy_between(mc, 0, ctx->lms_ctx_far + off, g, mc->ctx[g]->lms_ctx_far, R[g] * sizeof(uint32_t), ctx->stream);
-            off += R[g];
-        }
+        // (the sorted pieces of the other ranks are here already: each rank pushed its own behind its sort, see above)
         if (G > 1) {
             uint64_t noff = m_far_total;
             for (int q = 0; q < G && !rc; q++) {

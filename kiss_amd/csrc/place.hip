@@ -20,7 +20,9 @@
 #ifdef KISS_HIP_HOOKS
 #define KISS_TRACE(...) __VA_ARGS__
 #define KISS_TRACE_ARG(ctx) , (ctx)->tie_dbg_on ? (ctx)->tie_dbg : (uint32_t *)nullptr
+#ifndef KISS_TT_NO_RUNS // (-DKISS_TT_NO_RUNS: the hooks build with k_near_tie_runs compiled as shipped -- the kernel the fault follows)
 #define KISS_TT_RUNS
+#endif
 #define KISS_TT_MARK
 #define KISS_TT_TABLE
 #else
@@ -372,6 +374,27 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_runs(const uint64_t *__
     })
 }
 
+// The run of a near-end suffix e is [run_start[e], near_idx[e]): its first member shares k bases with e, the far suffix in
+// front of it does not.  Two probes per suffix check what k_near_tie_runs found with ~30 -- in its own kernel, with its own
+// code: round 4 traced the wrong exact-order results of two contexts sorting at once on one device to launches
+// of k_near_tie_runs that left EMPTY runs for every lane of their wave although every input and every scalar of the wave
+// reads correctly microseconds later; the tie marks of the exact order hang on these runs, so they are verified before they
+// are used and the search is repeated when they do not hold.
+__global__ __launch_bounds__(PL_THREADS) void k_near_tie_verify(const uint64_t *__restrict__ pk, uint64_t n, uint64_t k,
+                                                               const uint32_t *__restrict__ far_sorted,
+                                                               const uint32_t *__restrict__ near_pos,
+                                                               const uint32_t *__restrict__ near_idx, uint32_t E,
+                                                               const uint32_t *__restrict__ run_start, uint32_t *__restrict__ bad)
+{
+    const uint32_t e = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (e >= E) return;
+    const uint64_t pe = near_pos[e], hi = near_idx[e], lo = run_start[e];
+    bool ok = lo <= hi;
+    if (ok && lo < hi) ok = shares_k(pk, n, k, far_sorted[lo], pe);
+    if (ok && lo > 0) ok = !shares_k(pk, n, k, far_sorted[lo - 1], pe);
+    if (!ok) atomicAdd(bad, 1u);
+}
+
 // far_ctx[j] |= taint for j in [run_start[e], near_idx[e]): NT_BLOCKS workgroups per near suffix, grid-stride over its run
 constexpr uint32_t NT_BLOCKS = 16;
 // (the grid is capped: with E in the millions -- a bounded k of several million bases -- NT_BLOCKS * E workgroups of 256
@@ -407,6 +430,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_tie_mark(const uint32_t *__
 } // namespace
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include <cstdlib>
@@ -462,6 +486,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__res
             q[4] = tt_hfar ? ((hi >= 1 ? tt_hfar[hi - 1] : 9u) | (hi >= 2 ? tt_hfar[hi - 2] : 9u) << 8 | (hi >= 3 ? tt_hfar[hi - 3] : 9u) << 16) : 0xFFFFFFFFu;
             q[5] = (hi >= 1 ? tt_ctx[hi - 1] >> 31 : 9u) | (hi >= 2 ? tt_ctx[hi - 2] >> 31 : 9u) << 8 | (hi >= 3 ? tt_ctx[hi - 3] >> 31 : 9u) << 16;
             q[6] = tab_pos[e];
+            q[7] = near_pos[e];
         }
         if (dbg) __syncthreads(); // (one workgroup, E <= 256: every thread has read its tab_pos[e] before any thread overwrites the array)
     )
@@ -475,6 +500,26 @@ __global__ __launch_bounds__(PL_THREADS) void k_near_table(const uint32_t *__res
 
 
 } // namespace
+
+// k_near_tie_runs, verified (k_near_tie_verify) and repeated if its runs do not hold: at most three searches
+static int near_tie_runs_verified(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, const uint32_t *near_pos, uint32_t E, unsigned egrid)
+{
+    uint32_t *bad = ctx->d_small + 62;
+    for (int attempt = 0;; attempt++) {
+        hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far,
+                           near_pos, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_R(KISS_TRACE_ARG(ctx)));
+        KTRY(kiss_zero_u32(ctx, bad, 1));
+        hipLaunchKernelGGL(k_near_tie_verify, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k, ctx->lms_sorted_far,
+                           near_pos, ctx->near_idx, E, ctx->near_tmp2, bad);
+        KCHECK(hipGetLastError());
+        KTRY(kiss_readback(ctx, bad, 1));
+        if (ctx->h_pinned[0] == 0) return KISS_HIP_OK;
+        ctx->stats.tie_run_retries++;
+        if (ctx->opts.debug)
+            fprintf(stderr, "[kiss_hip] near-end tie runs: %u of %u runs do not hold (search %d), searching again\n", ctx->h_pinned[0], E, attempt + 1);
+        if (attempt == 2) return KINTERNAL();
+    }
+}
 
 int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
 {
@@ -514,8 +559,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                ctx->lms_sorted_far, m_far, near_sorted, E, ctx->near_idx);
             hipLaunchKernelGGL(k_near_fin_sorted, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
-                hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_sorted, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_R(, (uint32_t *)nullptr));
+                KTRY(near_tie_runs_verified(ctx, n, k, near_sorted, E, egrid));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
                                    ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_M(, (uint32_t *)nullptr));
             }
@@ -541,8 +585,7 @@ int kiss_place_lms(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
             hipLaunchKernelGGL(k_near_order, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k, near_pos,
                                ctx->near_idx, E, ctx->near_fin);
             if (m_far && (uint64_t)k < n) {
-                hipLaunchKernelGGL(k_near_tie_runs, dim3(egrid), dim3(PL_THREADS), 0, ctx->stream, ctx->pk, n, (uint64_t)k,
-                                   ctx->lms_sorted_far, near_pos, ctx->near_idx, E, ctx->near_tmp2 KISS_TRACE_R(KISS_TRACE_ARG(ctx)));
+                KTRY(near_tie_runs_verified(ctx, n, k, near_pos, E, egrid));
                 hipLaunchKernelGGL(k_near_tie_mark, dim3(tie_grid), dim3(PL_THREADS), 0, ctx->stream, ctx->near_tmp2, ctx->near_idx,
                                    ctx->lms_ctx_far, E, (k == ctx->h_depth) ? ctx->hfar : (uint8_t *)nullptr KISS_TRACE_M(KISS_TRACE_ARG(ctx)));
             }
@@ -622,6 +665,53 @@ void kiss_tie_trace_report(kiss_hip_ctx *ctx)
         return;
     const uint32_t E = ctx->tie_dbg_E < TT_MAX_E ? ctx->tie_dbg_E : TT_MAX_E;
     const uint64_t n = ctx->n, k = ctx->tie_dbg_k;
+#ifndef KISS_TT_RUNS
+    // k_near_tie_runs compiled as shipped (no recorder in it): one line per sort with what the mark kernel read and what the
+    // table kernel found afterwards, for the near-end suffixes that can tie; the stress harness compares the lines of one text
+    {
+        std::string line;
+        char buf[1024];
+        unsigned can = 0, stale = 0, nomark = 0;
+        for (uint32_t e = 0; e < E; e++) {
+            const uint32_t *q = &h[TT_MARK + 4 * e], *p = &h[TT_POST + 8 * e];
+            if (n - p[7] < k) continue;
+            can++;
+            if (q[0] != p[6]) stale++;                         // the mark kernel read another run start than the table kernel
+            if (p[4] != 0xFFFFFFFFu && (p[4] & 0xFF) != 0) nomark++; // far[hi - 1] still a group head
+            if (can <= 2) {
+                snprintf(buf, sizeof buf, " [e %u pos %u: mark read lo %u hi %u; afterwards run start %u hi %u far %u %u %u hfar %06x taint %06x]",
+                         e, p[7], q[0], q[1], p[6], p[0], p[1], p[2], p[3], p[4], p[5]);
+                line += buf;
+            }
+        }
+#ifdef KISS_TT_RUNS_ASM_RECORD
+        // the variant whose k_near_tie_runs was patched at the assembly level (tools/repro/patch_runs_asm.py): behind its last
+        // store every lane leaves 16 words of its wave state at run_start[1024 + 16 e ..] -- the shipped instruction
+        // sequence in front of it is untouched
+        {
+            std::vector<uint32_t> w(32 * (size_t)E);
+            if (hipMemcpyAsync(w.data(), ctx->near_tmp2 + 1024, w.size() * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                unsigned shown = 0;
+                for (uint32_t e = 0; e < E && shown < 2; e++) {
+                    const uint32_t *p = &h[TT_POST + 8 * e], *r = &w[32 * (size_t)e];
+                    if (n - p[7] < k) continue;
+                    shown++;
+                    snprintf(buf, sizeof buf, " {asm e %u: mask %08x%08x pk %08x%08x n %08x%08x k %08x%08x far %08x%08x pe %u lo %u v16 %u exec %08x%08x tag %08x | "
+                                              "far[lo-1] again: plain %u coherent %u | its pk word plain %08x%08x coherent %08x%08x | pk word of pe plain %08x%08x coherent %08x%08x}",
+                             e, r[1], r[0], r[3], r[2], r[5], r[4], r[7], r[6], r[9], r[8], r[10], r[11], r[12], r[14], r[13], r[15], r[16], r[17],
+                             r[19], r[18], r[21], r[20], r[23], r[22], r[25], r[24]);
+                    line += buf;
+                }
+            }
+        }
+#endif
+        fprintf(stderr, "[kiss_hip] tie_trace2 ctx %p n %llu k %llu E %u (mark kernel saw E %u hfar %u): can tie %u, mark/table disagree %u, "
+                        "far[hi-1] unmarked %u; mark start tick %u table start tick %u%s\n",
+                (void *)ctx, (unsigned long long)n, (unsigned long long)k, ctx->tie_dbg_E, h[4], h[5], can, stale, nomark, h[6], h[3], line.c_str());
+        return;
+    }
+#endif
     unsigned bad_read = 0, bad_list = 0, bad_mark = 0, can_tie = 0, empty_runs = 0;
     uint32_t runs_end = 0;
     bool have_end = false;
@@ -637,7 +727,6 @@ void kiss_tie_trace_report(kiss_hip_ctx *ctx)
         if (p[1] != r[2] || p[2] != r[4] || p[3] != r[5] || p[0] != r[1]) bad_list++;
         if (r[1] - r[0] >= 2 && ((p[5] & 0xFF) != 1 || (p[4] != 0xFFFFFFFFu && (p[4] & 0xFF) != 0))) bad_mark++;
     }
-    // clock order: last thread of the runs kernel < first workgroup of the mark kernel < table kernel
     const bool order_bad = (can_tie && ((int32_t)(h[6] - runs_end) < 0 || (int32_t)(h[3] - h[6]) < 0));
     const bool hdr_bad = h[0] != ctx->tie_dbg_E || h[4] != ctx->tie_dbg_E || h[1] != (uint32_t)k;
     const bool anomaly = bad_read || bad_list || bad_mark || order_bad || hdr_bad;

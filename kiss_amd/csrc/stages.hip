@@ -10,6 +10,7 @@
 // Stability across the exchange (receiver concatenates in source-rank order = ascending text position) keeps
 // the reference's position tie-break (include/biovoltron/algo/sort/kiss1_core.hpp:131-133).
 #include "kiss_internal.hpp"
+#include <mutex>
 #include <cstring>
 
 namespace {
@@ -123,6 +124,10 @@ int kiss_hip_stage_classify(kiss_hip_ctx *ctx, const uint8_t *d_S, uint64_t n, u
     if (!ctx || !d_S || !counts13 || n == 0 || n > ctx->max_n || lo > hi || hi > n) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;
@@ -190,6 +195,10 @@ int kiss_hip_stage_key_hist(kiss_hip_ctx *ctx, const uint64_t *d_keys, uint64_t 
     if (!ctx || !d_hist || bits < 1 || bits > 24 || (count && !d_keys)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;
@@ -208,6 +217,10 @@ int kiss_hip_stage_partition(kiss_hip_ctx *ctx, const uint64_t *d_keys, const ui
     if (count > ctx->m_cap) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;
@@ -230,6 +243,10 @@ int kiss_hip_stage_sort(kiss_hip_ctx *ctx, const uint64_t *d_keys, const uint32_
     if (count && (!d_keys || !d_pos || !d_sorted_out)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;
@@ -271,6 +288,10 @@ static int stage_induce_impl(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint32_t
     if ((m_far && !d_far_sorted) || (near_count && !d_near_pos)) return KISS_HIP_E_INVALID;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;
@@ -340,6 +361,10 @@ int kiss_hip_stage_refine_exact(kiss_hip_ctx *ctx, uint64_t n, uint32_t h0, uint
     if (h0 < 32 || n < 4ull * h0 + 1024) return KISS_HIP_E_UNSUPPORTED;
     KCHECK(hipSetDevice(ctx->device));
     kiss_opts_refresh(ctx);
+    // one device phase at a time per device and process, like sort_dev (api.hip): a stage call returns
+    // synchronised, so the lock is held for exactly its device work
+    std::unique_lock<std::mutex> device_lock;
+    if (!ctx->opts.no_serialize) device_lock = std::unique_lock<std::mutex>(kiss_device_mutex(ctx->device));
     ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
     ctx->hfar = ctx->hmerged = nullptr; // (tie flags of an exact-order sort_dev: never a stage call's, see api.hip)
     ctx->h_depth = 0;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = kiss_amd.load()
-    assert lib.kiss_hip_version() == 102
+    assert lib.kiss_hip_version() == 103
     assert _lib.strerror(0) == "ok"
     assert "invalid" in _lib.strerror(-1)
 
@@ -67,7 +67,7 @@ def test_ctypes_structs_match_the_header():
     assert ctypes.sizeof(_lib.FmiView) == _sizeof_from_header("kiss_hip_fmi_view")
     assert ctypes.sizeof(_lib.MultiStats) == _sizeof_from_header("kiss_hip_multi_stats")
     # and the field the Python side reads last sits where the header puts it
-    assert _lib.Stats.ms_refine.offset == ctypes.sizeof(_lib.Stats) - 24
+    assert _lib.Stats.ms_refine.offset == ctypes.sizeof(_lib.Stats) - 32 and _lib.Stats.tie_run_retries.offset == ctypes.sizeof(_lib.Stats) - 8
 
 
 def test_cpp_host_facade_compiles_and_links(tmp_path):

@@ -134,3 +134,23 @@ def test_ranks_stuck_in_a_collective_are_terminated_after_the_rank_timeout(monke
     args = argparse.Namespace(gpus=2, mode="sharded", no_fallback=False, rank_timeout=3.0)
     assert bench.parent_main(args, ["--gpus", "2"], child_cmd=STUB) == 124
     assert time.time() - t0 < 60
+
+
+def test_scaling_model_of_the_sharded_line():
+    # the expected-curve inputs every N > 1 line carries (bench.py: scaling_model): two GPUs share one link for
+    # the exchange and the gather and are expected SLOWER than one; from four GPUs on the sharded phases win; the ceiling is
+    # what stays on rank 0 (pack + induction)
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_model", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    m = {G: b.scaling_model(G, b.CHM13_N) for G in (1, 2, 4, 8)}
+    assert m[2]["expected_ms"] > m[1]["expected_ms"] > m[4]["expected_ms"] > m[8]["expected_ms"]
+    assert m[1]["exchange_bytes_per_rank"] == 0 and m[1]["gather_bytes_into_rank0"] == 0
+    assert abs(m[2]["exchange_bytes_per_rank"] - 12 * b.MODEL_LMS_FRACTION * b.CHM13_N / 4) < 1e6   # half of a rank's half
+    assert abs(m[8]["gather_bytes_into_rank0"] - 8 * b.MODEL_LMS_FRACTION * b.CHM13_N * 7 / 8) < 1e6
+    assert 3.0 < m[8]["ceiling_speedup"] < 4.0 and "model only" in m[8]["status"]
+    # a text of another length scales the phases with n
+    assert abs(b.scaling_model(4, b.CHM13_N // 2)["expected_ms"] - m[4]["expected_ms"] / 2) < 0.3
