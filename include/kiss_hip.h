@@ -16,8 +16,13 @@
  * Conventions: every function returns 0 (KISS_HIP_OK) or a negative kiss_hip_status.
  * No exceptions cross the ABI.  Host buffers are owned by the caller.  Device
  * workspace is owned by a kiss_hip_ctx.  A ctx is bound to one HIP device and must
- * not be used from two threads at once; distinct ctxs are independent (the device phases of two sorts on ONE device
- * queue up behind each other -- DESIGN.md 4.2 --, transfers and queries overlap).
+ * not be used from two threads at once; distinct ctxs are independent.  Inside one process the device phases of
+ * sorts on ONE device -- kiss_hip_*suffix_sort*, every kiss_hip_stage_* call, every phase of kiss_hip_multi_* -- queue up
+ * behind a per-device lock (a sort fills the GPU, two at once gain nothing); uploads, downloads, verification and queries
+ * run side by side.  The lock is per PROCESS: two processes may sort on one GPU at the same time, and so may the caller's own
+ * kernels on other streams; the results are the same (what round 3 saw go wrong there was a 16-byte load at
+ * an 8-byte aligned address in one kernel, gone since round 4; the near-end tie runs are verified before they are used,
+ * kiss_hip_stats.tie_run_retries).
  */
 #ifndef KISS_HIP_H
 #define KISS_HIP_H

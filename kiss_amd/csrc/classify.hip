@@ -55,11 +55,22 @@ struct WordMasks {
     uint64_t B;  // adder operand (lt at HI positions)
 };
 
-__device__ __forceinline__ WordMasks word_masks(const uint64_t *__restrict__ pk, uint64_t w, uint64_t n)
+// Consecutive lanes hold consecutive words (both callers: w = tile base + threadIdx.x), so a lane loads ITS word only -- one
+// naturally aligned 8-byte load (never a 16-byte load at an 8-byte aligned address) -- and takes the next
+// word from the next lane; lane 63 loads it.  ALL lanes of the wave must call (words >= `words` read as zero: the spare words
+// behind the text are zero).
+__device__ __forceinline__ WordMasks word_masks(const uint64_t *__restrict__ pk, uint64_t w, uint64_t n, uint64_t words)
 {
     WordMasks m;
-    uint64_t x, nx;
-    kiss_words2(pk, w, x, nx); // (aligned loads: kiss_internal.hpp)
+    const uint64_t x = w < words ? pk[w] : 0ull;
+    uint64_t nx = __shfl_down(x, 1, 64);
+    if (lane_id() == 63) nx = w + 1 < words ? pk[w + 1] : 0ull;
+    if (w >= words) { // (beyond the text: the neutral element of the carry chain)
+        m.x = 0;
+        m.A = LO;
+        m.B = 0;
+        return m;
+    }
     uint64_t y = (x << 2) | (nx >> 62); // field j of y = base 32w+j+1
     uint64_t d = x ^ y;
     uint64_t eqh = ~d & HI;
@@ -148,9 +159,7 @@ __global__ __launch_bounds__(CL_THREADS) void k_tile_gp(const uint64_t *__restri
 {
     __shared__ uint32_t lds[8];
     uint64_t w = (uint64_t)blockIdx.x * CL_THREADS + threadIdx.x;
-    WordMasks m;
-    if (w < words) m = word_masks(pk, w, n);
-    else { m.x = 0; m.A = LO; m.B = 0; }
+    const WordMasks m = word_masks(pk, w, n, words);
     uint64_t sum;
     uint32_t c0 = word_carry(m.A, m.B, 0, &sum);
     uint32_t c1 = word_carry(m.A, m.B, 1, &sum);
@@ -274,11 +283,10 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
     (void)tiles;
     for (uint64_t tile = tile_lo + blockIdx.x; tile < tile_hi; tile += gridDim.x) {
         uint64_t w = tile * CL_THREADS + threadIdx.x;
-        WordMasks m;
-        if (w < words) m = word_masks(pk, w, n);
-        else { m.x = 0; m.A = LO; m.B = 0; }
+        const WordMasks m = word_masks(pk, w, n, words);
         uint64_t T = tile_types(m, tile_cin[tile], lds);
-        uint64_t px = (w > 0 && w <= words) ? pk[w - 1] : 0ull;
+        uint64_t px = __shfl_up(m.x, 1, 64); // (the previous word: from the previous lane, lane 0 loads it)
+        if (lane_id() == 0) px = (w > 0 && w <= words) ? pk[w - 1] : 0ull;
         // window mask at LO positions: fields j with win_lo <= 32w + j < win_hi
         uint64_t W = 0;
         if (w < words) {
