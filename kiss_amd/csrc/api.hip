@@ -236,7 +236,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
 void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
-    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, ctx->CTX, ctx->ind_counts, ctx->ind_desc,
+    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->cl_part, ctx->d_counts, ctx->CTX, ctx->ind_counts, ctx->ind_desc,
                     ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->near_tmp2, ctx->pairs1, ctx->pairs2, ctx->rx_ctl, ctx->refine_heads, ctx->ga_codes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -686,6 +686,8 @@ int kiss_hip_ctx_create_sized(kiss_hip_ctx **out, int device, uint64_t max_n, ui
         ALLOC(pk, words);
         ALLOC(tile_gp, ctx->n_tiles_cap);
         ALLOC(tile_cnt, ctx->n_tiles_cap);
+        // rows of per-workgroup partial sums of the classification (classify.hip: <= 8192 workgroups x 1280 words)
+        ALLOC(cl_part, (ctx->n_tiles_cap < 8192 ? ctx->n_tiles_cap : 8192) * (uint64_t)(KISS_R0_PASSES * 256));
         ALLOC(d_counts, 16);
         ALLOC(ind_counts, ctx->ind_tiles_cap);
         ctx->ind_desc_stride = (max_n + 1) / 1024 + 2;

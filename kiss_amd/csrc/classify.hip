@@ -264,7 +264,8 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                                                         uint64_t win_lo, uint64_t win_hi, // only positions in [lo, hi)
                                                         uint64_t tile_lo, uint64_t tile_hi, // = the tiles that overlap it
                                                         uint32_t *__restrict__ lms_pos, uint64_t *__restrict__ lms_key,
-                                                        uint32_t *__restrict__ ghist) // emit: round-0 digit histograms
+                                                        uint32_t *__restrict__ ghist, // emit: round-0 digit histograms
+                                                        uint32_t *__restrict__ part)  // per-workgroup partial sums (see below)
 {
     // The emit pass also counts the five 8-bit digits round 0 of the LMS sort will scatter on (key bits 24..63 of the
     // far suffixes), so the radix sort does not read the 7 GB of keys once more just to count them (radix.hip).
@@ -276,6 +277,10 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
     __shared__ uint32_t lds[8];
     __shared__ uint32_t wsum[CL_THREADS / 64 + 1];
     __shared__ uint16_t stage[EMIT ? CL_THREADS * 16 : 1]; // offsets of the tile's LMS positions (<= 16 per word)
+    // emit: the word in front of the tile, the tile's words, the word behind it -- a key and its context word are cut from
+    // three neighbouring words, and a chain of L2 round trips per item (two 24-byte windows of the packed text) was what
+    // the pass waited for (round 4: 64 % of its wave cycles parked, SQ_WAIT_ANY)
+    __shared__ uint64_t xs[EMIT ? CL_THREADS + 2 : 1];
     uint32_t acc[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) acc[i] = 0;
@@ -287,6 +292,11 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
         uint64_t T = tile_types(m, tile_cin[tile], lds);
         uint64_t px = __shfl_up(m.x, 1, 64); // (the previous word: from the previous lane, lane 0 loads it)
         if (lane_id() == 0) px = (w > 0 && w <= words) ? pk[w - 1] : 0ull;
+        if (EMIT) { // (read after the barriers below; the last reader of the previous tile is behind the loop's last barrier)
+            xs[threadIdx.x + 1] = m.x;
+            if (threadIdx.x == 0) xs[0] = px;
+            if (threadIdx.x == CL_THREADS - 1) xs[CL_THREADS + 1] = w + 1 < words ? pk[w + 1] : 0ull;
+        }
         // window mask at LO positions: fields j with win_lo <= 32w + j < win_hi
         uint64_t W = 0;
         if (w < words) {
@@ -356,11 +366,18 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
             const uint64_t gbase = tile_cnt[tile];
             const uint64_t tbase = tile * (uint64_t)CL_THREADS * 32;
             for (uint32_t idx = threadIdx.x; idx < tile_total; idx += CL_THREADS) {
-                uint64_t pos = tbase + stage[idx];
+                const uint32_t lb = stage[idx]; // base offset inside the tile
+                uint64_t pos = tbase + lb;
                 lms_pos[gbase + idx] = (uint32_t)pos;
                 // first 32 bases; the 24 bits round 0 does not sort on carry the preceding 11 bases (kiss_internal.hpp)
-                const uint64_t key = kiss_key32(pk, pos);
-                lms_key[gbase + idx] = (key & ~KISS_KEY_CTX_MASK) | kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
+                const uint32_t lw = lb >> 5, sh = (lb & 31u) * 2u;
+                const uint64_t wp = xs[lw], wa = xs[lw + 1], wb = xs[lw + 2];
+                const uint64_t key = (wa << sh) | ((wb >> 1) >> (63u - sh));      // = kiss_key32(pk, pos)
+                const uint64_t before = (wp << sh) | ((wa >> 1) >> (63u - sh));   // the 32 bases in front of pos
+                constexpr uint32_t CB = 2u * KISS_KEY_CTX_BASES;
+                const uint32_t cw = pos >= KISS_KEY_CTX_BASES ? ((uint32_t)before & ((1u << CB) - 1u)) | (1u << CB)
+                                                              : kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
+                lms_key[gbase + idx] = (key & ~KISS_KEY_CTX_MASK) | cw;
                 if (ghist && pos <= far_limit) {
 #pragma unroll
                     for (int p = 0; p < KISS_R0_PASSES; p++)
@@ -370,20 +387,45 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
             __syncthreads();
         }
     }
+    // Totals leave as one row of partial sums per workgroup (k_sum_rows adds the rows up): thousands of workgroups adding
+    // to the same 13 / 1280 words with device-scope atomics queue up at the memory side.
     if (EMIT && ghist) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < KISS_R0_PASSES * 256; i += CL_THREADS)
-            if (hh[i]) atomicAdd(&ghist[i], hh[i]);
+            part[(uint64_t)blockIdx.x * (KISS_R0_PASSES * 256) + i] = hh[i];
     }
     if (!EMIT) {
+        __shared__ uint32_t wacc[CL_THREADS / 64][16];
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             uint32_t v = acc[i];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            if (lane_id() == 0 && v) atomicAdd(&d_counts[i], v);
+            if (lane_id() == 0) wacc[threadIdx.x >> 6][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            uint32_t v = 0;
+            if (threadIdx.x < 13)
+                for (int wv = 0; wv < CL_THREADS / 64; wv++) v += wacc[wv][threadIdx.x];
+            part[(uint64_t)blockIdx.x * 16 + threadIdx.x] = v;
         }
     }
+}
+
+// out[c] += sum over rows of part[row][c]  (rows x cols words, cols <= gridDim.x * 256; gridDim.y slabs of rows, one
+// atomic per slab and column)
+__global__ __launch_bounds__(256) void k_sum_rows(const uint32_t *__restrict__ part, uint32_t rows, uint32_t cols,
+                                                  uint32_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const uint32_t per = (rows + gridDim.y - 1) / gridDim.y;
+    const uint32_t r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    uint32_t v = 0;
+#pragma unroll 8
+    for (uint32_t r = r0; r < r1; r++) v += part[(uint64_t)r * cols + c];
+    if (v) atomicAdd(&out[c], v);
 }
 
 } // namespace
@@ -421,6 +463,7 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
     if (tile_hi < tile_lo || win_hi <= win_lo) tile_hi = tile_lo;
     const uint64_t wtiles = tile_hi - tile_lo;
     KTRY(kiss_zero_u32(ctx, ctx->d_counts, 16));
+    uint32_t *part = ctx->cl_part; // rows of per-workgroup partial sums (<= 8192 x 1280 words, api.hip)
     {
         KTimer t(ctx, KISS_HIP_K_CLASSIFY, n);
         hipLaunchKernelGGL(k_tile_gp, dim3((unsigned)tiles), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words,
@@ -439,7 +482,8 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
             unsigned grid = (unsigned)(wtiles < 2048 ? wtiles : 2048);
             hipLaunchKernelGGL(k_classify<false>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n, words, tiles,
                                ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, tile_lo, tile_hi,
-                               (uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+                               (uint32_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, part);
+            hipLaunchKernelGGL(k_sum_rows, dim3(1, 32), dim3(256), 0, ctx->stream, part, grid, 16u, ctx->d_counts);
         }
         KCHECK(hipGetLastError());
     }
@@ -460,7 +504,10 @@ int kiss_classify(kiss_hip_ctx *ctx, uint64_t n, uint64_t depth, uint64_t win_lo
         const unsigned grid = (unsigned)(wtiles < 8192 ? wtiles : 8192);
         hipLaunchKernelGGL(k_classify<true>, dim3(grid), dim3(CL_THREADS), 0, ctx->stream, ctx->pk, n,
                            words, tiles, ctx->tile_gp, ctx->tile_cnt, ctx->d_counts, far_limit, win_lo, win_hi, tile_lo, tile_hi,
-                           ctx->lms_pos, ctx->keyA, hist ? ctx->rx_ghist : (uint32_t *)nullptr);
+                           ctx->lms_pos, ctx->keyA, hist ? ctx->rx_ghist : (uint32_t *)nullptr, part);
+        if (hist)
+            hipLaunchKernelGGL(k_sum_rows, dim3(KISS_R0_PASSES, 64), dim3(256), 0, ctx->stream, part, grid,
+                               (uint32_t)(KISS_R0_PASSES * 256), ctx->rx_ghist);
         KCHECK(hipGetLastError());
         if (hist) ctx->rx_ghist_count = ctx->m_far; // consumed (or dropped) by the next kiss_radix_sort call
     }

@@ -135,6 +135,7 @@ struct kiss_hip_ctx {
     // classification scratch
     uint32_t *tile_gp = nullptr;   // per 256-word tile: bit0 = G, bit1 = P  -> later: carry-in of the tile
     uint32_t *tile_cnt = nullptr;  // per tile LMS count -> exclusive offsets
+    uint32_t *cl_part = nullptr;   // classification: one row of partial sums per workgroup (classify.hip: k_sum_rows)
     uint64_t n_tiles_cap = 0;
     uint32_t *d_counts = nullptr;  // 16 x u32: cnt[4], cntS[4], cntLMS[4], far_lms, spare
     // LMS arrays

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_pivot_heads(const uint64_t *__re
 // flags again, wave-ballot prefix inside the tile, survivors compacted, singletons retired.
 constexpr int FC_THREADS = 256;
 constexpr int FC_ITEMS = 8;
+constexpr int FC_ITEMS_DEFAULT = FC_ITEMS;
 constexpr int FC_TILE = FC_THREADS * FC_ITEMS;
 
 // where a segment starts: FC_KEY = the key changes, FC_KEY_SEG = the key or the segment id changes,
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc_compact(const uint64_t *__res
 // A thread owns FC_ITEMS consecutive items (two keys per load, four positions per load); survivor ranks come from a
 // wave prefix of the per-thread counts.  Every slot gets its position (a tied suffix's slot is rewritten when it
 // retires later) and its context word (0 while tied), so the stores are plain 16-byte streams.
+template <int FC_ITEMS = FC_ITEMS_DEFAULT>
 __device__ __forceinline__ void fc0_load(const uint64_t *__restrict__ key, uint64_t i0, uint64_t count, int cmp_shift,
                                          uint64_t k[FC_ITEMS + 2], uint32_t &valid, uint32_t *low = nullptr)
 {
@@ -686,6 +688,7 @@ __device__ __forceinline__ void fc0_load(const uint64_t *__restrict__ key, uint6
     k[FC_ITEMS + 1] = (valid && i0 + FC_ITEMS < count) ? (key[i0 + FC_ITEMS] >> cmp_shift) : 0ull;
 }
 
+template <int FC_ITEMS = FC_ITEMS_DEFAULT>
 __device__ __forceinline__ void fc0_flags(const uint64_t k[FC_ITEMS + 2], uint64_t i0, uint64_t count, uint32_t valid,
                                           uint32_t &survmask, uint32_t &headmask)
 {
@@ -824,11 +827,38 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
 // are numbered by an atomic ticket, so every predecessor of a running tile is running or done, and the wait is bounded
 // like the radix look-back (radix.hip) -- an error flag instead of a hung GPU.  The host learns the totals only
 // afterwards, so stores beyond `cap` (the tied-segment arrays) are dropped; the caller regrows and runs the pass again.
-constexpr int FC1_THREADS = 1024;
-constexpr int FC1_TILE = FC1_THREADS * FC_ITEMS; // 8192
+// Layout (round 4): STRIPED.  A lane takes two neighbouring items per 16-byte key load and the 64 lanes of a wave take
+// 128 neighbouring items per load instruction (1 KiB, every byte of every line used); a wave owns FC1_ITEMS / 2 such
+// chunks.  The blocked form of round 3 (a thread owned 8 neighbouring items = 64 bytes, so ONE load instruction of a wave
+// touched 64 different lines and used 16 bytes of each; the 16 waves' 64 KiB of lines did not fit the 32 KiB L1) spent
+// its time re-fetching lines from L2: 7.4 ms for 17 GB, and 10.4 / 15.3 ms with 16 / 32 items per thread.  Flags come
+// from one lane shift of the keys per chunk, ranks from ballots; a wave's stores of one chunk go to consecutive
+// survivor slots.  The survivor order (rank = tied items in front, in list order) is the same as before.
+#ifndef KISS_FC1_THREADS
+#define KISS_FC1_THREADS 1024
+#endif
+#ifndef KISS_FC1_ITEMS
+#define KISS_FC1_ITEMS 8
+#endif
+#ifndef KISS_FC1_MIN_WAVES
+#define KISS_FC1_MIN_WAVES 1
+#endif
+constexpr int FC1_THREADS = KISS_FC1_THREADS;
+constexpr int FC1_ITEMS = KISS_FC1_ITEMS;
+constexpr int FC1_CHUNKS = FC1_ITEMS / 2;         // chunks of 128 items per wave
+constexpr int FC1_WAVE_ITEMS = 64 * FC1_ITEMS;    // 512
+constexpr int FC1_TILE = FC1_THREADS * FC1_ITEMS; // 8192
 constexpr uint32_t FC1_SPIN_LIMIT = 1u << 22;
+static_assert(FC1_ITEMS % 2 == 0 && FC1_ITEMS <= 16, "two items per lane and chunk; four flag bits per chunk in one word");
 
-__global__ __launch_bounds__(FC1_THREADS) void k_fc0_onepass(const uint64_t *__restrict__ key,
+__device__ __forceinline__ uint64_t lane_value_u64(uint64_t v, int src_lane) // (the same lane in all callers)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass(const uint64_t *__restrict__ key,
                                                             const uint32_t *__restrict__ pos, uint64_t count,
                                                             int cmp_shift, uint64_t tiles, uint64_t *__restrict__ desc,
                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
@@ -846,39 +876,80 @@ __global__ __launch_bounds__(FC1_THREADS) void k_fc0_onepass(const uint64_t *__r
     if (tile >= tiles) return;
     const int wave = threadIdx.x >> 6;
     const uint32_t lane = lane_id();
-    const uint64_t i0 = (tile * FC1_THREADS + threadIdx.x) * FC_ITEMS;
-    uint64_t k[FC_ITEMS + 2];
-    uint32_t valid, sm, hm;
-    uint32_t p[FC_ITEMS], cw[FC_ITEMS];
-    fc0_load(key, i0, count, cmp_shift, k, valid, cw);
-    fc0_flags(k, i0, count, valid, sm, hm);
-    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
-    uint32_t is = ns, ih = nh; // inclusive wave prefixes
+    const uint64_t wbase = tile * FC1_TILE + (uint64_t)wave * FC1_WAVE_ITEMS; // first item of my wave
+    const bool full = wbase + FC1_WAVE_ITEMS <= count;                        // (wave-uniform)
+    uint64_t k0[FC1_CHUNKS], k1[FC1_CHUNKS]; // compared bits of my two items of chunk j
+    uint32_t c0[FC1_CHUNKS], c1[FC1_CHUNKS]; // their payload: the low KISS_KEY_CTX bits (cmp_shift >= 24 in round 0)
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
-        if ((int)lane >= d) {
-            is += os;
-            ih += oh;
+    for (int j = 0; j < FC1_CHUNKS; j++) {
+        const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
+        ulonglong2 kk;
+        if (full) kk = *reinterpret_cast<const ulonglong2 *>(key + a);
+        else {
+            kk.x = a < count ? key[a] : 0ull;
+            kk.y = a + 1 < count ? key[a + 1] : 0ull;
+        }
+        k0[j] = kk.x >> cmp_shift;
+        k1[j] = kk.y >> cmp_shift;
+        c0[j] = (uint32_t)(kk.x & KISS_KEY_CTX_MASK);
+        c1[j] = (uint32_t)(kk.y & KISS_KEY_CTX_MASK);
+    }
+    // the items either side of my wave's stretch
+    const bool has_prev = wbase > 0 && wbase < count, has_next = wbase + FC1_WAVE_ITEMS < count;
+    const uint64_t kprev = has_prev ? key[wbase - 1] >> cmp_shift : 0ull;
+    const uint64_t knext = has_next ? key[wbase + FC1_WAVE_ITEMS] >> cmp_shift : 0ull;
+    // the positions are not needed before the offsets are known: their loads overlap the flags and the look-back
+    uint32_t p0[FC1_CHUNKS], p1[FC1_CHUNKS];
+#pragma unroll
+    for (int j = 0; j < FC1_CHUNKS; j++) {
+        const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
+        if (full) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(pos + a);
+            p0[j] = t.x;
+            p1[j] = t.y;
+        } else {
+            p0[j] = a < count ? pos[a] : 0u;
+            p1[j] = a + 1 < count ? pos[a + 1] : 0u;
         }
     }
-    if (lane == 63) {
-        ws[wave][0] = is;
-        ws[wave][1] = ih;
+    // head(i) = item i starts a segment (differs from item i - 1; items past the end count as heads)
+    uint64_t H0[FC1_CHUNKS]; // ballot of head(first item of the lane), per chunk
+    uint32_t h01 = 0;        // my own head bits: bit 2j = first item, bit 2j + 1 = second item of chunk j
+#pragma unroll
+    for (int j = 0; j < FC1_CHUNKS; j++) {
+        const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
+        uint64_t up = __shfl_up(k1[j], 1, 64); // the second item of the lane below
+        const uint64_t before = j == 0 ? kprev : lane_value_u64(k1[j > 0 ? j - 1 : 0], 63);
+        if (lane == 0) up = before;
+        const bool h0 = a == 0 || a >= count || up != k0[j];
+        const bool h1 = a + 1 >= count || k0[j] != k1[j];
+        H0[j] = __ballot(h0);
+        h01 |= (h0 ? 1u : 0u) << (2 * j) | (h1 ? 1u : 0u) << (2 * j + 1);
     }
-    // the positions are not needed before the offsets are known: their loads overlap the look-back
-    if (valid == FC_ITEMS) {
+    const bool next_head = !has_next || lane_value_u64(k1[FC1_CHUNKS - 1], 63) != knext; // head(first item after my wave)
+    // survivors (tied with a neighbour) and the heads among them; ranks inside the wave
+    uint32_t fl = 0;                              // bits 4j .. 4j+3: surv0, surv1, headsurv0, headsurv1
+    uint32_t rs[FC1_CHUNKS], gs[FC1_CHUNKS];      // survivors / surviving heads of my wave in front of my first item of chunk j
+    uint32_t run_s = 0, run_h = 0;                // (wave-uniform running totals)
+    const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int q = 0; q < FC_ITEMS / 4; q++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(pos + i0 + 4 * q);
-            p[4 * q] = t.x;
-            p[4 * q + 1] = t.y;
-            p[4 * q + 2] = t.z;
-            p[4 * q + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++) p[e] = (uint32_t)e < valid ? pos[i0 + e] : 0u;
+    for (int j = 0; j < FC1_CHUNKS; j++) {
+        const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
+        const bool h0 = (h01 >> (2 * j)) & 1u, h1 = (h01 >> (2 * j + 1)) & 1u;
+        const uint64_t nxt = j + 1 < FC1_CHUNKS ? H0[j + 1 < FC1_CHUNKS ? j + 1 : j] : (next_head ? 1ull : 0ull);
+        const bool hn = lane < 63u ? ((H0[j] >> (lane + 1u)) & 1ull) != 0 : (nxt & 1ull) != 0; // head(item after my second)
+        const bool s0 = a < count && !(h0 && h1), s1 = a + 1 < count && !(h1 && hn);
+        const bool m0 = s0 && h0, m1 = s1 && h1;
+        const uint64_t S0 = __ballot(s0), S1 = __ballot(s1), M0 = __ballot(m0), M1 = __ballot(m1);
+        rs[j] = run_s + (uint32_t)__popcll(S0 & below) + (uint32_t)__popcll(S1 & below);
+        gs[j] = run_h + (uint32_t)__popcll(M0 & below) + (uint32_t)__popcll(M1 & below);
+        run_s += (uint32_t)__popcll(S0) + (uint32_t)__popcll(S1);
+        run_h += (uint32_t)__popcll(M0) + (uint32_t)__popcll(M1);
+        fl |= ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (m0 ? 4u : 0u) | (m1 ? 8u : 0u)) << (4 * j);
+    }
+    if (lane == 0) {
+        ws[wave][0] = run_s;
+        ws[wave][1] = run_h;
     }
     __syncthreads();
     uint32_t ts = 0, th = 0, ws0 = 0, wh0 = 0; // tile totals; totals of the waves before mine
@@ -939,32 +1010,40 @@ __global__ __launch_bounds__(FC1_THREADS) void k_fc0_onepass(const uint64_t *__r
         }
     }
     __syncthreads();
-    if (valid == 0) return;
-    uint32_t bs = s_excl[0] + ws0 + (is - ns), bh = s_excl[1] + wh0 + (ih - nh);
+    if (wbase >= count) return;
+    const uint32_t bs = s_excl[0] + ws0, bh = s_excl[1] + wh0;
 #pragma unroll
-    for (int e = 0; e < FC_ITEMS; e++) {
-        if ((sm >> e) & 1u) {
-            const uint32_t ni = bs++;
-            if ((hm >> e) & 1u) bh++;
-            const uint32_t sid = bh - 1u; // heads up to and including this item's own segment head
-            if (ni < cap) {
-                npos[ni] = p[e];
-                nslot[ni] = (uint32_t)(i0 + e);
-                nseg[ni] = sid;
-                if ((hm >> e) & 1u) nsegstart[sid] = ni;
-                if (nctx) nctx[ni] = cw[e]; // travels with the tied item through the first refinement round
+    for (int j = 0; j < FC1_CHUNKS; j++) {
+        const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
+        const uint32_t f = (fl >> (4 * j)) & 15u;
+        const uint32_t ni0 = bs + rs[j], ni1 = ni0 + (f & 1u);
+        const uint32_t sid0 = bh + gs[j] + ((f >> 2) & 1u) - 1u;   // heads up to and including the item's own, minus one
+        const uint32_t sid1 = sid0 + ((f >> 3) & 1u);
+        if (f & 1u) {
+            if (ni0 < cap) {
+                npos[ni0] = p0[j];
+                nslot[ni0] = (uint32_t)a;
+                nseg[ni0] = sid0;
+                if (f & 4u) nsegstart[sid0] = ni0;
+                if (nctx) nctx[ni0] = c0[j]; // travels with the tied item through the first refinement round
             }
-            cw[e] = 0; // tied so far: written when the item is finished, else gathered at placement
+            c0[j] = 0; // tied so far: written when the item is finished, else gathered at placement
         }
-    }
-    if (valid == FC_ITEMS) {
-#pragma unroll
-        for (int q = 0; q < FC_ITEMS / 4; q++)
-            *reinterpret_cast<uint4 *>(octx + i0 + 4 * q) = make_uint4(cw[4 * q], cw[4 * q + 1], cw[4 * q + 2], cw[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < FC_ITEMS; e++)
-            if ((uint32_t)e < valid) octx[i0 + e] = cw[e];
+        if (f & 2u) {
+            if (ni1 < cap) {
+                npos[ni1] = p1[j];
+                nslot[ni1] = (uint32_t)(a + 1);
+                nseg[ni1] = sid1;
+                if (f & 8u) nsegstart[sid1] = ni1;
+                if (nctx) nctx[ni1] = c1[j];
+            }
+            c1[j] = 0;
+        }
+        if (full) *reinterpret_cast<uint2 *>(octx + a) = make_uint2(c0[j], c1[j]);
+        else {
+            if (a < count) octx[a] = c0[j];
+            if (a + 1 < count) octx[a + 1] = c1[j];
+        }
     }
 }
 
