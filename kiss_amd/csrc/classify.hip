@@ -365,23 +365,37 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
             __syncthreads();
             const uint64_t gbase = tile_cnt[tile];
             const uint64_t tbase = tile * (uint64_t)CL_THREADS * 32;
-            for (uint32_t idx = threadIdx.x; idx < tile_total; idx += CL_THREADS) {
-                const uint32_t lb = stage[idx]; // base offset inside the tile
-                uint64_t pos = tbase + lb;
-                lms_pos[gbase + idx] = (uint32_t)pos;
-                // first 32 bases; the 24 bits round 0 does not sort on carry the preceding 11 bases (kiss_internal.hpp)
-                const uint32_t lw = lb >> 5, sh = (lb & 31u) * 2u;
-                const uint64_t wp = xs[lw], wa = xs[lw + 1], wb = xs[lw + 2];
-                const uint64_t key = (wa << sh) | ((wb >> 1) >> (63u - sh));      // = kiss_key32(pk, pos)
-                const uint64_t before = (wp << sh) | ((wa >> 1) >> (63u - sh));   // the 32 bases in front of pos
-                constexpr uint32_t CB = 2u * KISS_KEY_CTX_BASES;
-                const uint32_t cw = pos >= KISS_KEY_CTX_BASES ? ((uint32_t)before & ((1u << CB) - 1u)) | (1u << CB)
-                                                              : kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES);
-                lms_key[gbase + idx] = (key & ~KISS_KEY_CTX_MASK) | cw;
-                if (ghist && pos <= far_limit) {
+            // two items per step (idx and idx + CL_THREADS): their LDS reads and stores overlap -- one item per step was a
+            // chain of three LDS round trips, and the waves of a workgroup all sat in it at once
+            constexpr uint32_t CB = 2u * KISS_KEY_CTX_BASES;
+            for (uint32_t idx = threadIdx.x; idx < tile_total; idx += 2 * CL_THREADS) {
+                const uint32_t idx2 = idx + CL_THREADS;
+                const bool two = idx2 < tile_total;
+                uint32_t lb[2] = {stage[idx], two ? stage[idx2] : 0u}; // base offsets inside the tile
+                uint64_t key[2];
+                uint32_t cw[2];
 #pragma unroll
-                    for (int p = 0; p < KISS_R0_PASSES; p++)
-                        atomicAdd(&hh[p * 256 + ((uint32_t)(key >> (KISS_R0_SHIFT + 8 * p)) & 255u)], 1u);
+                for (int u = 0; u < 2; u++) {
+                    // first 32 bases; the 24 bits round 0 does not sort on carry the preceding 11 bases (kiss_internal.hpp)
+                    const uint32_t lw = lb[u] >> 5, sh = (lb[u] & 31u) * 2u;
+                    const uint64_t wp = xs[lw], wa = xs[lw + 1], wb = xs[lw + 2];
+                    key[u] = (wa << sh) | ((wb >> 1) >> (63u - sh));                 // = kiss_key32(pk, pos)
+                    const uint64_t before = (wp << sh) | ((wa >> 1) >> (63u - sh)); // the 32 bases in front of pos
+                    cw[u] = ((uint32_t)before & ((1u << CB) - 1u)) | (1u << CB);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (u == 1 && !two) break;
+                    const uint64_t pos = tbase + lb[u];
+                    if (pos < KISS_KEY_CTX_BASES) cw[u] = kiss_load_ctx_n(pk, pos, KISS_KEY_CTX_BASES); // (the text's first bases)
+                    const uint64_t o = gbase + idx + (uint32_t)u * CL_THREADS;
+                    lms_pos[o] = (uint32_t)pos;
+                    lms_key[o] = (key[u] & ~KISS_KEY_CTX_MASK) | cw[u];
+                    if (ghist && pos <= far_limit) {
+#pragma unroll
+                        for (int p = 0; p < KISS_R0_PASSES; p++)
+                            atomicAdd(&hh[p * 256 + ((uint32_t)(key[u] >> (KISS_R0_SHIFT + 8 * p)) & 255u)], 1u);
+                    }
                 }
             }
             __syncthreads();

@@ -136,6 +136,18 @@ __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__
     return ((emitmask >> pc) & 1u) ? pc : 4u;
 }
 
+// inclusive prefix sum over the 64 lanes of the wave (all lanes must call): six v_add_u32_dpp
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true); // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // ---- pass 1: per-tile class counts ---------------------------------------------------
 // One WAVE per tile (a workgroup = IN_WAVES tiles): counting does not care about order, so a lane takes four
 // consecutive items per step (16-byte loads, all of the tile's steps in flight at once) and keeps the four class
@@ -168,6 +180,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
     if (block) {
         U4 t[STEPS];
         int64_t p0[STEPS];
+        uint32_t least = 0xFFFFFFFFu; // (a word without bases: refreshed from the text -- rare, one test per wave)
 #pragma unroll
         for (int q = 0; q < STEPS; q++) {
             const uint64_t i0 = t0 + (uint64_t)q * 256 + 4 * lane;
@@ -175,27 +188,47 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
             t[q] = *reinterpret_cast<const U4 *>(srcC + p0[q]);
         }
 #pragma unroll
-        for (int q = 0; q < STEPS; q++) {
+        for (int q = 0; q < STEPS; q++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const uint32_t c = t[q].v[e];
-                uint32_t cls;
-                if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class_only<false>(pk, srcP, srcC, p0[q] + e, emitmask, rm); // refresh path
-                else {
-                    const uint32_t pc = c & 3u;
-                    cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+            for (int e = 0; e < 4; e++) least = min(least, t[q].v[e] & 0x7FFFFFFEu);
+        uint32_t cnt8 = 0; // my items per class, 8-bit fields (a lane has 32 items of the tile)
+        if (__ballot(least == 0u) == 0ull) {
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t pc = t[q].v[e] & 3u;
+                    cnt8 += ((emitmask >> pc) & 1u) << (pc << 3);
                 }
-                acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t c = t[q].v[e];
+                    uint32_t cls;
+                    if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class_only<false>(pk, srcP, srcC, p0[q] + e, emitmask, rm); // refresh path
+                    else {
+                        const uint32_t pc = c & 3u;
+                        cls = ((emitmask >> pc) & 1u) ? pc : 4u;
+                    }
+                    cnt8 += (cls < 4u ? 1u : 0u) << ((cls & 3u) << 3);
+                }
             }
         }
+        static_assert(IN_TILE / 64 <= 255, "8-bit counters per lane");
+        acc = (uint64_t)((cnt8 & 0xFFu) | ((cnt8 & 0xFF00u) << 8)) | ((uint64_t)(((cnt8 >> 16) & 0xFFu) | ((cnt8 >> 8) & 0xFF0000u)) << 32);
     } else {
         for (uint64_t i = t0 + lane; i < N && i < t0 + IN_TILE; i += 64) {
             const uint32_t cls = item_class_only<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, rm);
             acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    // totals of the wave: two DPP prefix sums over the 16-bit fields, the last lane holds the sums
+    const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add((uint32_t)acc), 63);
+    const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add((uint32_t)(acc >> 32)), 63);
+    acc = ((uint64_t)shi << 32) | slo;
     if (lane < 4) counts[(uint64_t)lane * tiles + tile] = (uint32_t)(acc >> (16 * lane)) & 0xFFFFu;
 }
 
@@ -204,14 +237,24 @@ struct DstPos {
 };
 
 // ---- pass 2: stable scatter ------------------------------------------------------------
-template <bool REMAP>
+// Round 4: the kernel was bound by its vector instructions, not by memory (SQ counters, profiles/r04_pmc_sq_*: 770 VALU
+// and 380 SALU instructions per wave of 512 items = the kernel's whole duration on the four SIMDs of a CU).  Rewritten
+// around packed arithmetic: the four class counters of a thread are 8-bit fields of one register, their wave prefixes
+// 16-bit fields of two (two 6-instruction DPP scans instead of four shuffle scans), an item's place in the staged tile is
+// one v_perm_b32 out of the packed bases plus its rank, and the direction of the sweep is a template parameter (the
+// reversal of a thread's items is register naming, not selects).
+template <bool REMAP, int DIR>
 __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *__restrict__ pk, const uint32_t *srcP,
-                                                              uint32_t *srcC, int64_t beg, uint64_t N, int dir,
+                                                              uint32_t *srcC, int64_t beg, uint64_t N,
                                                               uint32_t emitmask, const uint32_t *__restrict__ ex,
                                                               uint64_t tiles, DstPos dst, uint32_t *SA, uint32_t *CTX,
                                                               uint32_t *__restrict__ totals, LmsRemap rm)
 {
-    __shared__ uint32_t wtot[IN_WAVES][4];
+    static_assert(IN_ITEMS == 8 && IN_WAVES == 4, "8-bit counters per thread, 4-bit ranks of a thread's items in one word");
+    static_assert(!REMAP || DIR > 0, "the LMS list is read left to right only");
+    __shared__ uint32_t wtot[IN_WAVES][2]; // class totals of a wave, packed: [0] = class 0 | class 1 << 16, [1] = 2 | 3 << 16
+    __shared__ __attribute__((aligned(16))) uint32_t stP[IN_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t stC[IN_TILE];
     // items appended per class = differences of the scanned counts (4 * tiles + 1 entries)
     if (blockIdx.x == 0 && threadIdx.x < 4) totals[threadIdx.x] = ex[(uint64_t)(threadIdx.x + 1) * tiles] - ex[(uint64_t)threadIdx.x * tiles];
     const int wave = threadIdx.x >> 6;
@@ -222,9 +265,17 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         uint32_t v[4];
     };
     const uint64_t i0 = (uint64_t)blockIdx.x * IN_TILE + (uint64_t)threadIdx.x * IN_ITEMS;
-    uint32_t vv[IN_ITEMS], cc[IN_ITEMS], rr[IN_ITEMS]; // rr = (class << 28) | rank in wave
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    int64_t shift = 0; // REMAP (dir > 0 only): see k_induce_count
+    uint32_t vv[IN_ITEMS], cc[IN_ITEMS]; // positions and context words, in the order of the pass
+    uint32_t okm = 0;                    // bit e: item e appends
+    uint32_t loc = 0;                    // bits 4e .. 4e+3: earlier items of my own with item e's class
+    uint32_t cnt8 = 0;                   // my items per class, 8-bit fields
+    auto take = [&](int e, uint32_t pc, uint32_t ok) { // class pc (meaningless when ok == 0)
+        const uint32_t sh = pc << 3;
+        loc |= ((cnt8 >> sh) & 15u) << (4 * e);
+        cnt8 += ok << sh;
+        okm |= ok << e;
+    };
+    int64_t shift = 0; // REMAP: see k_induce_count
     bool block = i0 + IN_ITEMS <= N;
     if (REMAP) {
         // first for the whole tile (one answer per wave, no dependent loads); only a tile that holds a near-end suffix
@@ -239,7 +290,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         }
     }
     if (block) {
-        const int64_t p0 = (dir > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1)) - shift; // lowest address of my items
+        const int64_t p0 = (DIR > 0 ? beg + (int64_t)i0 : beg - (int64_t)(i0 + IN_ITEMS - 1)) - shift; // lowest address of my items
         uint32_t bp[IN_ITEMS], bc[IN_ITEMS];
 #pragma unroll
         for (int q = 0; q < IN_ITEMS / 4; q++) {
@@ -251,119 +302,120 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
                 bc[4 * q + e] = tcw.v[e];
             }
         }
+        // a context word that has run out of bases is refreshed from the text: rare, so ONE test for the whole wave
+        // decides between the straight-line form and the one with a branch per item
+        uint32_t least = 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < IN_ITEMS; e++) {
-            const int a = dir > 0 ? e : IN_ITEMS - 1 - e; // place of item e inside the block
-            uint32_t v = bp[a], c = bc[a], cls;
-            if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm); // refresh path
-            else {
-                const uint32_t pc = c & 3u;
-                cls = ((emitmask >> pc) & 1u) ? pc : 4u;
-            }
-            uint32_t local = 0;
+        for (int e = 0; e < IN_ITEMS; e++) least = min(least, bc[e] & 0x7FFFFFFEu);
+        static_assert(KISS_EMPTY_CTX == 1u && KISS_CTX_TAINT == 0x80000000u, "no bases <=> all bits but 0 and 31 clear");
+        constexpr int last = IN_ITEMS - 1;
+        if (__ballot(least == 0u) == 0ull) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (cls == (uint32_t)k) local = cnt[k];
-                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
+            for (int e = 0; e < IN_ITEMS; e++) {
+                const int a = DIR > 0 ? e : last - e; // place of item e inside the block
+                const uint32_t pc = bc[a] & 3u;
+                take(e, pc, (emitmask >> pc) & 1u);
+                vv[e] = bp[a];
+                cc[e] = bc[a];
             }
-            vv[e] = v;
-            cc[e] = c;
-            rr[e] = (cls << 28) | local;
+        } else {
+#pragma unroll
+            for (int e = 0; e < IN_ITEMS; e++) {
+                const int a = DIR > 0 ? e : last - e;
+                uint32_t v = bp[a], c = bc[a];
+                if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) { // refresh path
+                    const uint32_t cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm);
+                    take(e, cls & 3u, cls < 4u ? 1u : 0u);
+                } else {
+                    const uint32_t pc = c & 3u;
+                    take(e, pc, (emitmask >> pc) & 1u);
+                }
+                vv[e] = v;
+                cc[e] = c;
+            }
         }
     } else {
 #pragma unroll
         for (int e = 0; e < IN_ITEMS; e++) {
             const uint64_t i = i0 + (uint64_t)e;
             uint32_t cls = 4u, v = 0, c = 0;
-            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, &v, &c, rm);
-            uint32_t local = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (cls == (uint32_t)k) local = cnt[k];
-                cnt[k] += cls == (uint32_t)k ? 1u : 0u;
-            }
+            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)DIR * (int64_t)i, emitmask, &v, &c, rm);
+            take(e, cls & 3u, cls < 4u ? 1u : 0u);
             vv[e] = v;
             cc[e] = c;
-            rr[e] = (cls << 28) | local;
         }
     }
-    uint32_t run[4]; // wave totals
-    uint32_t lex[4]; // items of class k in lower lanes
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t inc = cnt[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if ((int)lane_id() >= d) inc += o;
-        }
-        lex[k] = inc - cnt[k];
-        run[k] = __shfl(inc, 63, 64);
-    }
-#pragma unroll
-    for (int e = 0; e < IN_ITEMS; e++) {
-        const uint32_t cls = rr[e] >> 28;
-        if (cls < 4u) rr[e] += cls == 0 ? lex[0] : (cls == 1 ? lex[1] : (cls == 2 ? lex[2] : lex[3]));
-    }
-    if (lane_id() == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) wtot[wave][c] = run[c];
+    // A refreshed or remapped item's class is the low two bits of its (new) context word whenever it appends, so from here
+    // on: class of item e = cc[e] & 3, valid where okm has bit e.
+    // wave prefixes of the four counters, as 16-bit fields (a tile has 2048 items)
+    const uint32_t mylo = (cnt8 & 0xFFu) | ((cnt8 & 0xFF00u) << 8), myhi = ((cnt8 >> 16) & 0xFFu) | ((cnt8 >> 8) & 0xFF0000u);
+    const uint32_t inlo = wave_scan_add(mylo), inhi = wave_scan_add(myhi);
+    if (lane_id() == 63) {
+        wtot[wave][0] = inlo;
+        wtot[wave][1] = inhi;
     }
     __syncthreads();
-    // stage the tile class by class in LDS, then write every class as one contiguous run (full 256-byte stores
-    // instead of 64-byte pieces per wave and iteration)
-    __shared__ uint32_t stP[IN_TILE], stC[IN_TILE];
-    uint32_t coff[5]; // start of class c inside the staged tile
-    uint32_t woff[4]; // this wave's start inside class c
-    coff[0] = 0;
+    // the tile staged class by class in LDS: class k starts at coff[k]; inside it the waves in order, inside a wave the lanes
+    uint32_t tlo = 0, thi = 0, olo = 0, ohi = 0; // totals of the tile / of the waves before mine
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        uint32_t t = 0, w0 = 0;
-        for (int w = 0; w < IN_WAVES; w++) {
-            if (w < wave) w0 += wtot[w][c];
-            t += wtot[w][c];
+    for (int w = 0; w < IN_WAVES; w++) {
+        const uint32_t a = wtot[w][0], b = wtot[w][1];
+        tlo += a;
+        thi += b;
+        if (w < wave) {
+            olo += a;
+            ohi += b;
         }
-        woff[c] = w0;
-        coff[c + 1] = coff[c] + t;
     }
+    const uint32_t c1 = tlo & 0xFFFFu, c2 = c1 + (tlo >> 16), c3 = c2 + (thi & 0xFFFFu), total = c3 + (thi >> 16);
+    // where my first item of class k goes, again as 16-bit fields (every sum stays below 2049)
+    const uint32_t blo = (c1 << 16) + olo + (inlo - mylo), bhi = (c2 | (c3 << 16)) + ohi + (inhi - myhi);
 #pragma unroll
-    for (int j = 0; j < IN_ITEMS; j++) {
-        const uint32_t cls = rr[j] >> 28;
-        if (cls < 4u) {
-            const uint32_t li = coff[cls] + woff[cls] + (rr[j] & 0x0FFFFFFFu);
-            stP[li] = vv[j] - 1u;
-            stC[li] = child_ctx(cc[j]);
+    for (int e = 0; e < IN_ITEMS; e++) {
+        if ((okm >> e) & 1u) {
+            const uint32_t pc = cc[e] & 3u;
+            const uint32_t base = __builtin_amdgcn_perm(bhi, blo, 0x0c0c0100u + pc * 0x0202u); // field pc of bhi:blo
+            const uint32_t li = base + ((loc >> (4 * e)) & 15u);
+            stP[li] = vv[e] - 1u;
+            stC[li] = child_ctx(cc[e]);
         }
     }
     __syncthreads();
     // write-out: a thread takes four consecutive staged items of one class and stores them with one 16-byte store
-    // per array (4-byte aligned); class boundaries and the tail fall back to single stores
-    const uint32_t total = coff[4];
-    for (uint32_t l0 = threadIdx.x * 4u; l0 < total; l0 += IN_THREADS * 4u) {
-        const uint32_t cls = l0 < coff[1] ? 0u : (l0 < coff[2] ? 1u : (l0 < coff[3] ? 2u : 3u));
-        const uint32_t cend = cls == 0 ? coff[1] : (cls == 1 ? coff[2] : (cls == 2 ? coff[3] : coff[4]));
-        if (l0 + 4u <= cend) {
-            const uint32_t toff = ex[(uint64_t)cls * tiles + blockIdx.x] - ex[(uint64_t)cls * tiles];
-            const uint32_t cstart = cls == 0 ? coff[0] : (cls == 1 ? coff[1] : (cls == 2 ? coff[2] : coff[3]));
-            const int64_t dp = cls == 0 ? dst.p[0] : (cls == 1 ? dst.p[1] : (cls == 2 ? dst.p[2] : dst.p[3]));
-            const int64_t d0 = dp + (int64_t)dir * (int64_t)(toff + (l0 - cstart)); // place of item l0; l0 + e at d0 + dir * e
-            U4 wp, wc;
+    // per array (4-byte aligned); class boundaries and the tail fall back to single stores.
+    // Staged item l of class k goes to db[k] + DIR * l  (db[k] = list head + DIR * (items of class k in earlier tiles - coff[k]))
+    int64_t db[4];
+    {
+        const uint32_t cs[4] = {0u, c1, c2, c3};
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int a = dir > 0 ? e : 3 - e;
-                wp.v[a] = stP[l0 + e];
-                wc.v[a] = stC[l0 + e];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t toff = ex[(uint64_t)k * tiles + blockIdx.x] - ex[(uint64_t)k * tiles];
+            db[k] = dst.p[k] + (int64_t)DIR * ((int64_t)toff - (int64_t)cs[k]);
+        }
+    }
+    for (uint32_t l0 = threadIdx.x * 4u; l0 < total; l0 += IN_THREADS * 4u) {
+        const uint32_t cls = (l0 >= c1 ? 1u : 0u) + (l0 >= c2 ? 1u : 0u) + (l0 >= c3 ? 1u : 0u);
+        const uint32_t cend = cls == 0 ? c1 : (cls == 1 ? c2 : (cls == 2 ? c3 : total));
+        if (l0 + 4u <= cend) {
+            const int64_t dbk = cls == 0 ? db[0] : (cls == 1 ? db[1] : (cls == 2 ? db[2] : db[3]));
+            const int64_t d0 = dbk + (int64_t)DIR * (int64_t)l0; // place of item l0; l0 + e at d0 + DIR * e
+            const uint4 sp = *reinterpret_cast<const uint4 *>(stP + l0), sc = *reinterpret_cast<const uint4 *>(stC + l0);
+            U4 wp, wc;
+            if (DIR > 0) {
+                wp.v[0] = sp.x, wp.v[1] = sp.y, wp.v[2] = sp.z, wp.v[3] = sp.w;
+                wc.v[0] = sc.x, wc.v[1] = sc.y, wc.v[2] = sc.z, wc.v[3] = sc.w;
+            } else {
+                wp.v[0] = sp.w, wp.v[1] = sp.z, wp.v[2] = sp.y, wp.v[3] = sp.x;
+                wc.v[0] = sc.w, wc.v[1] = sc.z, wc.v[2] = sc.y, wc.v[3] = sc.x;
             }
-            const int64_t lo = dir > 0 ? d0 : d0 - 3;
+            const int64_t lo = DIR > 0 ? d0 : d0 - 3;
             *reinterpret_cast<U4 *>(SA + lo) = wp;
             *reinterpret_cast<U4 *>(CTX + lo) = wc;
         } else {
             for (uint32_t li = l0; li < l0 + 4u && li < total; li++) {
-                const uint32_t c2 = li < coff[1] ? 0u : (li < coff[2] ? 1u : (li < coff[3] ? 2u : 3u));
-                const uint32_t toff = ex[(uint64_t)c2 * tiles + blockIdx.x] - ex[(uint64_t)c2 * tiles];
-                const uint32_t cstart = c2 == 0 ? coff[0] : (c2 == 1 ? coff[1] : (c2 == 2 ? coff[2] : coff[3]));
-                const int64_t dp = c2 == 0 ? dst.p[0] : (c2 == 1 ? dst.p[1] : (c2 == 2 ? dst.p[2] : dst.p[3]));
-                const int64_t d = dp + (int64_t)dir * (int64_t)(toff + (li - cstart));
+                const uint32_t c2_ = (li >= c1 ? 1u : 0u) + (li >= c2 ? 1u : 0u) + (li >= c3 ? 1u : 0u);
+                const int64_t dbk = c2_ == 0 ? db[0] : (c2_ == 1 ? db[1] : (c2_ == 2 ? db[2] : db[3]));
+                const int64_t d = dbk + (int64_t)DIR * (int64_t)li;
                 SA[d] = stP[li];
                 CTX[d] = stC[li];
             }
@@ -749,11 +801,14 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
         {
             KTimer t(ctx, KISS_HIP_K_INDUCE_SCATTER, N);
             if (remap)
-                hipLaunchKernelGGL(k_induce_scatter<true>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                                   srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                hipLaunchKernelGGL((k_induce_scatter<true, 1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+            else if (sw.dir > 0)
+                hipLaunchKernelGGL((k_induce_scatter<false, 1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
             else
-                hipLaunchKernelGGL(k_induce_scatter<false>, dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                                   srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                hipLaunchKernelGGL((k_induce_scatter<false, -1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
             KCHECK(hipGetLastError());
         }
         }

@@ -808,3 +808,32 @@ def test_exact_order_taint_shortcut_equals_comparing_every_pair(oracle, monkeypa
         with kiss_amd.MultiContext([0, 0], max_n=n) as mc:
             assert np.array_equal(mc.suffix_sort(S, 0xFFFFFFFF, algo=1), want)
     monkeypatch.delenv("KISS_HIP_NO_TAINT", raising=False)
+
+
+@pytest.mark.gpu
+def test_staged_and_multi_sort_after_an_exact_sort_of_a_sparser_text(oracle):
+    """An exact-order sort leaves tie flags behind (one byte per far LMS suffix, at the far end of the context-word array,
+    sized for THAT text's LMS count).  A staged sort and a multi-device sort of a text of the same length with four times
+    as many LMS suffixes, on the same contexts, must not mark through the stale pointer (stages.hip, multi.hip
+    reset ctx->hfar / h_depth at every entry)."""
+    import torch
+    import kiss_amd
+    from kiss_amd import multi_gpu
+    n = 600_000
+    rng = np.random.default_rng(5)
+    sparse = np.repeat(rng.integers(0, 4, n // 8 + 1, dtype=np.uint8), 8)[:n].copy()  # runs of 8: one LMS per ~30 bases
+    dense = gen.iid(n, 9)
+    with kiss_amd.Context(max_n=n, device=0) as c:
+        assert np.array_equal(c.suffix_sort(sparse, 0xFFFFFFFF, algo=1), oracle.suffix_sort(sparse, 0xFFFFFFFF))
+        m_sparse = c.stats()["m"]
+        d_S = torch.from_numpy(dense).to(torch.device("cuda", 0))
+        be = multi_gpu.GpuBackend(c, d_S, 256)
+        counts = be.classify(0, n)
+        keys, pos, m_far = be.local_lms()
+        assert m_far > 2 * m_sparse
+        srt, cw = be.sort(keys[:m_far], pos[:m_far])
+        SA = be.induce(srt, pos[m_far:].clone(), counts[:12], far_ctx=cw)
+        assert np.array_equal(SA.cpu().numpy().view(np.uint32), oracle.suffix_sort(dense, 256))
+    with kiss_amd.MultiContext([0, 0], max_n=n) as mc:
+        assert np.array_equal(mc.suffix_sort(sparse, 0xFFFFFFFF, algo=1), oracle.suffix_sort(sparse, 0xFFFFFFFF))
+        assert np.array_equal(mc.suffix_sort(dense, 256), oracle.suffix_sort(dense, 256))
