@@ -843,6 +843,9 @@ __global__ __launch_bounds__(FC_THREADS) void k_fc0_compact(const uint64_t *__re
 #ifndef KISS_FC1_MIN_WAVES
 #define KISS_FC1_MIN_WAVES 1
 #endif
+#ifndef KISS_FC1_STORE_UNROLL
+#define KISS_FC1_STORE_UNROLL 4 // (= all chunks; 1 saves 12 registers and buys no second workgroup per CU)
+#endif
 constexpr int FC1_THREADS = KISS_FC1_THREADS;
 constexpr int FC1_ITEMS = KISS_FC1_ITEMS;
 constexpr int FC1_CHUNKS = FC1_ITEMS / 2;         // chunks of 128 items per wave
@@ -851,6 +854,20 @@ constexpr int FC1_TILE = FC1_THREADS * FC1_ITEMS; // 8192
 constexpr uint32_t FC1_SPIN_LIMIT = 1u << 22;
 static_assert(FC1_ITEMS % 2 == 0 && FC1_ITEMS <= 16, "two items per lane and chunk; four flag bits per chunk in one word");
 
+#ifdef FC_PROF
+// -DFC_PROF (tools/build_prof.sh): wall-clock ticks between the phase boundaries of a tile, summed over all tiles by thread 0
+__device__ unsigned long long fc_prof[12];
+#define FC_MARK(i)                                                                                                     \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            const unsigned long long now_ = wall_clock64();                                                            \
+            atomicAdd(&fc_prof[i], now_ - t_prev_);                                                                    \
+            t_prev_ = now_;                                                                                            \
+        }                                                                                                              \
+    } while (0)
+#else
+#define FC_MARK(i)
+#endif
 __device__ __forceinline__ uint64_t lane_value_u64(uint64_t v, int src_lane) // (the same lane in all callers)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
@@ -870,8 +887,12 @@ __global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass
     __shared__ uint32_t ws[FC1_THREADS / 64][2];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_excl[2];
+#ifdef FC_PROF
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
+    FC_MARK(0); // ticket + barrier
     const uint64_t tile = s_tile;
     if (tile >= tiles) return;
     const int wave = threadIdx.x >> 6;
@@ -912,6 +933,10 @@ __global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass
             p1[j] = a + 1 < count ? pos[a + 1] : 0u;
         }
     }
+#ifdef FC_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FC_MARK(1); // keys, neighbours and positions have arrived
+#endif
     // head(i) = item i starts a segment (differs from item i - 1; items past the end count as heads)
     uint64_t H0[FC1_CHUNKS]; // ballot of head(first item of the lane), per chunk
     uint32_t h01 = 0;        // my own head bits: bit 2j = first item, bit 2j + 1 = second item of chunk j
@@ -951,7 +976,9 @@ __global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass
         ws[wave][0] = run_s;
         ws[wave][1] = run_h;
     }
+    FC_MARK(2); // flags and ranks of my wave
     __syncthreads();
+    FC_MARK(3); // ... of the slowest wave
     uint32_t ts = 0, th = 0, ws0 = 0, wh0 = 0; // tile totals; totals of the waves before mine
 #pragma unroll
     for (int w = 0; w < FC1_THREADS / 64; w++) {
@@ -1009,10 +1036,12 @@ __global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass
             if (tile + 1 == tiles) total[0] = ((es + ts) << 32) | (eh + th);
         }
     }
+    FC_MARK(4); // look-back (wave 0)
     __syncthreads();
+    FC_MARK(5);
     if (wbase >= count) return;
     const uint32_t bs = s_excl[0] + ws0, bh = s_excl[1] + wh0;
-#pragma unroll
+#pragma unroll KISS_FC1_STORE_UNROLL
     for (int j = 0; j < FC1_CHUNKS; j++) {
         const uint64_t a = wbase + (uint64_t)j * 128 + 2 * lane;
         const uint32_t f = (fl >> (4 * j)) & 15u;
@@ -1045,6 +1074,11 @@ __global__ __launch_bounds__(FC1_THREADS, KISS_FC1_MIN_WAVES) void k_fc0_onepass
             if (a + 1 < count) octx[a + 1] = c1[j];
         }
     }
+    FC_MARK(6); // stores issued
+#ifdef FC_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FC_MARK(7); // stores done
+#endif
 }
 
 // ---- tie flags as bytes (the doubling phase's first compaction over all n + 1 suffixes): 8 flags per load, and the
@@ -1337,6 +1371,18 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                 KCHECK(hipGetLastError());
             }
             KTRY(fc_read_total(ctx, d_total, &tot));
+#ifdef FC_PROF
+            {
+                unsigned long long h[12], z[12] = {0};
+                KCHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(fc_prof), sizeof h));
+                KCHECK(hipMemcpyToSymbol(HIP_SYMBOL(fc_prof), z, sizeof z));
+                unsigned long long sum = 0;
+                for (int i = 0; i < 8; i++) sum += h[i];
+                fprintf(stderr, "[fc_prof] %llu tiles, %.2f us per tile (100 MHz clock):", (unsigned long long)tiles1, (double)sum / 100.0 / (double)tiles1);
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %d:%.1f%%", i, sum ? 100.0 * (double)h[i] / (double)sum : 0.0);
+                fprintf(stderr, "\n");
+            }
+#endif
             if ((tot >> 32) <= ctx->t_cap) break;
             if (attempt) return KINTERNAL();
             // more tied suffixes than the tied-segment arrays hold (their stores were dropped): regrow, once more
