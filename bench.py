@@ -534,6 +534,45 @@ def assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof
     return out
 
 
+def agree_on_rehearsal(dist, torch, device, local_ok, local_msg):
+    """every rank contributes whether ITS part of the rehearsal went well; all ranks return the same verdict: None when
+    all did, else a reason (the rank's own when it has one)"""
+    if dist.get_backend() == "gloo":  # (the CPU / one-GPU tests)
+        device = torch.device("cpu")
+    flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return None
+    return local_msg or "the rehearsal failed on another rank"
+
+
+def rehearse_sharded(torch, dist, kiss_amd, S, n, k, rank, local_rank, device):
+    """The sharded pipeline has never met a second GPU.  Before anything is timed, the ranks sort the first
+    8 M bases of the text through it -- every collective and every stage entry point, small messages -- and rank 0
+    checks the result on the device.  The ranks agree on the outcome; a failure that all ranks survive (a wrong suffix
+    array, an error code, an exception raised on every rank) turns the run into --mode replicas, said so in the line
+    (config.sharded_error).  A collective that never completes is not survivable: that is what --rank-timeout is for."""
+    from kiss_amd import multi_gpu
+    ns = int(min(n, 8_000_000))
+    ok, msg = True, None
+    try:
+        Ss = S[:ns]
+        c = kiss_amd.Context(max_n=ns, device=local_rank)
+        try:
+            sa = torch.empty(ns + 1, dtype=torch.int32, device=device) if rank == 0 else None
+            multi_gpu.sharded_suffix_sort(multi_gpu.GpuBackend(c, Ss, k), ns, SA=sa)
+            torch.cuda.synchronize()
+            if rank == 0:
+                rep = c.verify_sa_dev(Ss.data_ptr(), ns, sa.data_ptr(), k)
+                if not rep["ok"]:
+                    ok, msg = False, "the rehearsal's suffix array fails the device-side check: %s" % json.dumps(rep)
+        finally:
+            c.close()
+    except Exception as e:  # noqa: BLE001 -- whatever it is, the ranks have to agree on what happens next
+        ok, msg = False, "rank %d: %s: %s" % (rank, type(e).__name__, e)
+    return agree_on_rehearsal(dist, torch, device, ok, msg)
+
+
 # 1-GPU phase times of the headline configuration (ms; DESIGN.md 4, round 4 records) and the xGMI rate DESIGN.md 7 prices
 # the two data-path transfers at: the inputs of the expected strong-scaling curve
 MODEL_1GPU_MS = {"pack": 0.65, "classify": 4.1, "sort": 52.7, "induce": 19.4, "histogram": 3.4, "partition": 5.6}
@@ -719,6 +758,9 @@ def main():
     ap.add_argument("--exact-steps", type=int, default=3)
     ap.add_argument("--fm-text-len", type=int, default=DM_N, help="text length of the FM-index leg (default: dm size)")
     ap.add_argument("--fm-queries", type=int, default=1_000_000)
+    ap.add_argument("--no-rehearsal", action="store_true",
+                    help="sharded runs on more than one GPU: skip the small rehearsal sort (and the agreed fall-back to "
+                         "--mode replicas when it fails) in front of the measurement")
     ap.add_argument("--no-fallback", action="store_true",
                     help="self-launching parent only: do not start fresh --mode replicas ranks after a sharded failure")
     ap.add_argument("--rank-timeout", type=float, default=1500.0,
@@ -801,6 +843,24 @@ def main():
     SA = torch.empty(n + 1, dtype=torch.int32, device=device)  # u32 payload; torch has no uint32 arithmetic needs
     torch.cuda.synchronize()
 
+    sharded_error = args.sharded_error  # set by the self-launching parent on its fresh replicas run, or just below
+    if sharded and world > 1 and not args.no_rehearsal:
+        err = rehearse_sharded(torch, dist, kiss_amd, S, n, k, rank, local_rank, device)
+        if err:
+            print("[bench] rank %d: sharded rehearsal failed (%s): every rank measures --mode replicas instead" % (rank, err),
+                  file=sys.stderr, flush=True)
+            sharded, sharded_error = False, "sharded rehearsal failed, all ranks fell back to replicas: " + err
+            if rank > 0 and not args.fasta:  # replicas sort independent texts (the file form: every rank its copy)
+                del S
+                seed = args.seed + 1000 * rank
+                if args.iid:
+                    g = torch.Generator(device=device)
+                    g.manual_seed(seed)
+                    S = torch.randint(0, 4, (n,), dtype=torch.uint8, device=device, generator=g)
+                else:
+                    S = gen_text_device(n, seed, device, harsh=args.harsh)
+                torch.cuda.synchronize()
+
     multi = None
     if args.multi_abi:
         if world > 1 or sharded:
@@ -836,7 +896,6 @@ def main():
 
     # A rank that fails here exits non-zero (the traceback goes to stderr): a process group whose collective has
     # failed is never used again, and there is no in-process retry in another mode.
-    sharded_error = args.sharded_error  # only ever set by the self-launching parent on its fresh replicas run
     for _ in range(args.warmup):
         step()
     if phase_ms is not None:

@@ -109,3 +109,33 @@ def test_bench_takes_a_fasta_path(tmp_path):
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
     assert out["data"] == "file" and out["config"]["n"] == S.size and "g.fa" in out["config"]["workload"]
     assert out["verified"] is True and out["value"] > 0 and out["exact_order"]["verified"] is True
+
+
+@pytest.mark.gpu
+def test_sharded_rehearsal_passes_on_one_rank_and_reports_a_failure(monkeypatch):
+    """bench.rehearse_sharded: the small sharded sort in front of an N > 1 measurement.  One rank (gloo group of one, the
+    only form a one-GPU box can run): the real stages sort 8 M bases, rank 0's device-side check passes -> None; with the
+    pipeline made to raise, the verdict is the reason (and every rank of a real job would get one)."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import kiss_amd
+    from kiss_amd import multi_gpu
+    sys.path.insert(0, ROOT)
+    sys.modules.pop("bench", None)
+    bench = importlib.import_module("bench")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29950 + os.getpid() % 40)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        n = 9_000_000
+        S = bench.gen_text_device(n, 2, dev)
+        assert bench.rehearse_sharded(torch, dist, kiss_amd, S, n, 256, 0, 0, dev) is None
+
+        def boom(*a, **kw):
+            raise RuntimeError("boom")
+        monkeypatch.setattr(multi_gpu, "sharded_suffix_sort", boom)
+        err = bench.rehearse_sharded(torch, dist, kiss_amd, S, n, 256, 0, 0, dev)
+        assert err is not None and "boom" in err and "rank 0" in err
+    finally:
+        dist.destroy_process_group()

@@ -154,3 +154,42 @@ def test_scaling_model_of_the_sharded_line():
     assert 3.0 < m[8]["ceiling_speedup"] < 4.0 and "model only" in m[8]["status"]
     # a text of another length scales the phases with n
     assert abs(b.scaling_model(4, b.CHM13_N // 2)["expected_ms"] - m[4]["expected_ms"] / 2) < 0.3
+
+
+def _rehearsal_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _bench()
+        dev = torch.device("cpu")
+        # round 1: every rank is fine; round 2: rank 1 reports a failure of its own; round 3: rank 0 does
+        r1 = b.agree_on_rehearsal(dist, torch, dev, True, None)
+        r2 = b.agree_on_rehearsal(dist, torch, dev, rank != 1, "rank 1: RuntimeError: boom" if rank == 1 else None)
+        r3 = b.agree_on_rehearsal(dist, torch, dev, rank != 0, "the rehearsal's suffix array fails" if rank == 0 else None)
+        q.put((rank, r1, r2, r3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_outcome_of_the_sharded_rehearsal():
+    """bench.py: before a sharded measurement on more than one GPU the ranks sort a small text through the sharded pipeline
+    and AGREE on whether that went well (all fall back to --mode replicas or none does).  gloo, world_size 2, on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    ps = [ctx.Process(target=_rehearsal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r1, r2, r3 in got:
+        assert r1 is None
+        assert r2 is not None and r3 is not None  # both ranks fall back, whoever saw the failure
+    assert got[1][2] == "rank 1: RuntimeError: boom" and "another rank" in got[0][2]
+    assert "suffix array fails" in got[0][3] and "another rank" in got[1][3]
