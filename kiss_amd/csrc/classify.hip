@@ -355,12 +355,18 @@ __global__ __launch_bounds__(CL_THREADS) void k_classify(const uint64_t *__restr
                 if (i < (int)(threadIdx.x >> 6)) loff += wsum[i];
                 tile_total += wsum[i];
             }
-            uint64_t mm = lmsmask;
-            while (mm) {
-                int bit = 63 - __clzll(mm); // highest set bit first = smallest position
-                mm &= ~(1ull << bit);
-                uint32_t j = (uint32_t)(62 - bit) >> 1;
-                stage[loff++] = (uint16_t)(threadIdx.x * 32 + j);
+            // highest set bit first = smallest position; the two halves of the word in turn (32-bit bit scans: the 64-bit
+            // form was a third of the pass's vector instructions)
+            const uint32_t tb = threadIdx.x * 32u;
+            for (uint32_t mh = (uint32_t)(lmsmask >> 32); mh;) {
+                const uint32_t lz = (uint32_t)__clz((int)mh); // bit 31 - lz of the high half
+                mh &= ~(0x80000000u >> lz);
+                stage[loff++] = (uint16_t)(tb + (lz >> 1)); // field = base index inside the word (two bits per base)
+            }
+            for (uint32_t ml = (uint32_t)lmsmask; ml;) {
+                const uint32_t lz = (uint32_t)__clz((int)ml);
+                ml &= ~(0x80000000u >> lz);
+                stage[loff++] = (uint16_t)(tb + 16u + (lz >> 1));
             }
             __syncthreads();
             const uint64_t gbase = tile_cnt[tile];
