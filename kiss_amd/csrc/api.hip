@@ -67,6 +67,7 @@ void kiss_opts_refresh(kiss_hip_ctx *ctx)
     o.pivot_from_round2 = env_on("KISS_HIP_PIVOT_FROM_ROUND2");
     o.pair_keys = env_on("KISS_HIP_PAIR_KEYS");
     o.no_fc0_onepass = env_on("KISS_HIP_NO_FC0_ONEPASS");
+    o.no_class_bytes = env_on("KISS_HIP_NO_CLASS_BYTES");
     o.no_pivot_ctx = env_on("KISS_HIP_NO_PIVOT_CTX");
     o.no_taint = env_on("KISS_HIP_NO_TAINT");
     o.isa_direct = env_on("KISS_HIP_ISA_DIRECT");
@@ -236,7 +237,7 @@ void free_lms_side(kiss_hip_ctx *ctx)
 void free_all(kiss_hip_ctx *ctx)
 {
     free_lms_side(ctx);
-    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->cl_part, ctx->d_counts, ctx->CTX, ctx->ind_counts, ctx->ind_desc,
+    void *ptrs[] = {ctx->pk, ctx->tile_gp, ctx->tile_cnt, ctx->cl_part, ctx->d_counts, ctx->CTX, ctx->CLS, ctx->ind_counts, ctx->ind_desc,
                     ctx->d_small, ctx->near_idx, ctx->near_fin, ctx->near_pos, ctx->near_tmp, ctx->near_tmp2, ctx->pairs1, ctx->pairs2, ctx->rx_ctl, ctx->refine_heads, ctx->ga_codes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -427,8 +428,11 @@ int kiss_workspace_ready(kiss_hip_ctx *ctx)
 // process that runs the induction: allocated on first use, so that ranks > 0 of a sharded sort never hold it
 int kiss_need_ctx_words(kiss_hip_ctx *ctx)
 {
-    if (ctx->CTX) return KISS_HIP_OK;
-    return dmalloc(ctx, &ctx->CTX, ctx->max_n + 2);
+    if (ctx->CTX && ctx->CLS) return KISS_HIP_OK;
+    if (!ctx->CTX) KTRY(dmalloc(ctx, &ctx->CTX, ctx->max_n + 2));
+    // one class byte per context word (induce.hip: cls_byte); + 64: the count pass reads whole aligned 16-byte pieces
+    if (!ctx->CLS) KTRY(dmalloc(ctx, &ctx->CLS, ctx->max_n + 2 + 64));
+    return KISS_HIP_OK;
 }
 
 int kiss_lms_reserve(kiss_hip_ctx *ctx, uint64_t m_cap, uint64_t t_cap_wanted)

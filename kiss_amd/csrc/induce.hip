@@ -41,6 +41,14 @@ __device__ __forceinline__ uint32_t child_ctx(uint32_t parent)
     return (KISS_CTX_WORD(parent) >> 2) | (parent & KISS_CTX_TAINT);
 }
 
+// One byte per context word written into the arrays parallel to SA (ctx->CLS, round 4): the word's class bits and a flag for
+// "no bases left" -- all the count pass needs of a word, so it reads 1 byte per item instead of 4.
+__device__ __forceinline__ uint32_t cls_byte(uint32_t c)
+{
+    return (c & 3u) | ((c & 0x7FFFFFFEu) == 0u ? 4u : 0u);
+}
+static_assert(KISS_EMPTY_CTX == 1u && KISS_CTX_TAINT == 0x80000000u, "no bases <=> all bits but 0 and 31 clear");
+
 // The sorted LMS list is read where the LMS sort left it (ctx->lms_sorted_far / lms_ctx_far) instead of from a merged copy
 // (place.hip): the handful of near-end suffixes, ranked by the scalar tail of the comparator, live in a small table
 // sorted by their index in the merged list.  Merged index j holds near-end suffix t if fin[t] == j, else far suffix
@@ -85,7 +93,7 @@ __device__ __forceinline__ uint32_t remap_below_wave(const LmsRemap &rm, uint64_
 template <bool REMAP>
 __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
                                                int64_t idx, uint32_t emitmask, uint32_t *v_out, uint32_t *ctx_out,
-                                               const LmsRemap &rm)
+                                               const LmsRemap &rm, uint8_t *srcK = nullptr)
 {
     int64_t phys = idx;
     if (REMAP) {
@@ -110,6 +118,7 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
         }
         c = kiss_load_ctx(pk, v) | (c & KISS_CTX_TAINT);
         srcC[phys] = c; // keep the refreshed word: the scatter pass (and the other sweep) reuse it
+        if (srcK) srcK[phys] = (uint8_t)cls_byte(c);
     }
     *ctx_out = c;
     uint32_t pc = c & 3u;
@@ -119,7 +128,7 @@ __device__ __forceinline__ uint32_t item_class(const uint64_t *__restrict__ pk, 
 // the count pass only needs the class: the position is read only when the context word has no bases
 template <bool REMAP>
 __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__ pk, const uint32_t *srcP, uint32_t *srcC,
-                                                    int64_t idx, uint32_t emitmask, const LmsRemap &rm)
+                                                    int64_t idx, uint32_t emitmask, const LmsRemap &rm, uint8_t *srcK = nullptr)
 {
     if (REMAP) {
         uint32_t v, c;
@@ -131,6 +140,7 @@ __device__ __forceinline__ uint32_t item_class_only(const uint64_t *__restrict__
         if (v == 0) return 4u;
         c = kiss_load_ctx(pk, v) | (c & KISS_CTX_TAINT);
         srcC[idx] = c;
+        if (srcK) srcK[idx] = (uint8_t)cls_byte(c);
     }
     const uint32_t pc = c & 3u;
     return ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -156,7 +166,7 @@ template <bool REMAP>
 __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__restrict__ pk, const uint32_t *srcP,
                                                             uint32_t *srcC, int64_t beg, uint64_t N, int dir,
                                                             uint32_t emitmask, uint32_t *__restrict__ counts,
-                                                            uint64_t tiles, LmsRemap rm)
+                                                            uint64_t tiles, LmsRemap rm, uint8_t *srcK)
 {
     if (blockIdx.x == 0 && threadIdx.x == 4) counts[4 * tiles] = 0; // the extra last entry of the scan input
     const uint64_t tile = (uint64_t)blockIdx.x * IN_WAVES + (threadIdx.x >> 6);
@@ -177,7 +187,55 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
         block = b0 == remap_below_wave(rm, (uint64_t)beg + t0 + IN_TILE);
         shift = (int64_t)b0;
     }
-    if (block) {
+    // srcK (may be null): one class byte per word of srcC (cls_byte).  A full tile then reads 2 KiB instead of 8: the
+    // byte stretch [A, A + 2048) as aligned 16-byte pieces -- two per lane, and a 129th for lane 0 when A is not aligned;
+    // bytes outside the stretch are replaced by 8 ("skip").  A byte that says "no bases left" sends the whole tile to
+    // the word path below, which refreshes the word (and its byte).
+    bool counted = false;
+    if (!REMAP && srcK != nullptr && block) { // (wave-uniform)
+        const int64_t lo_index = dir > 0 ? beg + (int64_t)t0 : beg - (int64_t)(t0 + IN_TILE - 1);
+        const uint8_t *const A = srcK + lo_index;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 15u);
+        const uint4 *const ap = reinterpret_cast<const uint4 *>(A - mis);
+        static_assert(IN_TILE == 2048, "64 lanes x 2 x 16 bytes");
+        uint32_t w[12];
+        {
+            const uint4 q0 = ap[lane], q1 = ap[64 + lane];
+            w[0] = q0.x, w[1] = q0.y, w[2] = q0.z, w[3] = q0.w;
+            w[4] = q1.x, w[5] = q1.y, w[6] = q1.z, w[7] = q1.w;
+            w[8] = w[9] = w[10] = w[11] = 0x08080808u;
+        }
+        if (mis != 0 && lane == 0) {
+            const uint4 q2 = ap[128];
+            const uint32_t tail[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int nb = (int)mis - 4 * i; // bytes of this word that lie below byte `mis` of the piece
+                const uint32_t lowmask = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ~(0xFFFFFFFFu << (8 * nb)));
+                w[i] = (w[i] & ~lowmask) | (0x08080808u & lowmask);         // first piece: in front of A
+                w[8 + i] = (tail[i] & lowmask) | (0x08080808u & ~lowmask);  // 129th piece: the stretch's last bytes
+            }
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) any |= w[i];
+        if (__ballot((any & 0x04040404u) != 0u) == 0ull) {
+            uint32_t cnt8 = 0; // (a lane has at most 48 items)
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t b = (w[i] >> (8 * e)) & 0xFFu;
+                    const uint32_t pc = b & 3u;
+                    cnt8 += ((emitmask >> pc) & ~(b >> 3) & 1u) << (pc << 3);
+                }
+            }
+            acc = (uint64_t)((cnt8 & 0xFFu) | ((cnt8 & 0xFF00u) << 8)) | ((uint64_t)(((cnt8 >> 16) & 0xFFu) | ((cnt8 >> 8) & 0xFF0000u)) << 32);
+            counted = true;
+        }
+    }
+    if (counted) {
+    } else if (block) {
         U4 t[STEPS];
         int64_t p0[STEPS];
         uint32_t least = 0xFFFFFFFFu; // (a word without bases: refreshed from the text -- rare, one test per wave)
@@ -208,7 +266,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
                 for (int e = 0; e < 4; e++) {
                     const uint32_t c = t[q].v[e];
                     uint32_t cls;
-                    if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class_only<false>(pk, srcP, srcC, p0[q] + e, emitmask, rm); // refresh path
+                    if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) cls = item_class_only<false>(pk, srcP, srcC, p0[q] + e, emitmask, rm, REMAP ? nullptr : srcK); // refresh path
                     else {
                         const uint32_t pc = c & 3u;
                         cls = ((emitmask >> pc) & 1u) ? pc : 4u;
@@ -221,7 +279,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_count(const uint64_t *__r
         acc = (uint64_t)((cnt8 & 0xFFu) | ((cnt8 & 0xFF00u) << 8)) | ((uint64_t)(((cnt8 >> 16) & 0xFFu) | ((cnt8 >> 8) & 0xFF0000u)) << 32);
     } else {
         for (uint64_t i = t0 + lane; i < N && i < t0 + IN_TILE; i += 64) {
-            const uint32_t cls = item_class_only<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, rm);
+            const uint32_t cls = item_class_only<REMAP>(pk, srcP, srcC, beg + (int64_t)dir * (int64_t)i, emitmask, rm, REMAP ? nullptr : srcK);
             acc += cls < 4u ? 1ull << (16 * cls) : 0ull;
         }
     }
@@ -248,7 +306,9 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
                                                               uint32_t *srcC, int64_t beg, uint64_t N,
                                                               uint32_t emitmask, const uint32_t *__restrict__ ex,
                                                               uint64_t tiles, DstPos dst, uint32_t *SA, uint32_t *CTX,
-                                                              uint32_t *__restrict__ totals, LmsRemap rm)
+                                                              uint32_t *__restrict__ totals, LmsRemap rm,
+                                                              uint8_t *CLS,  // class bytes parallel to CTX (may be null)
+                                                              uint8_t *srcK) // ... parallel to srcC (may be null)
 {
     static_assert(IN_ITEMS == 8 && IN_WAVES == 4, "8-bit counters per thread, 4-bit ranks of a thread's items in one word");
     static_assert(!REMAP || DIR > 0, "the LMS list is read left to right only");
@@ -324,7 +384,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
                 const int a = DIR > 0 ? e : last - e;
                 uint32_t v = bp[a], c = bc[a];
                 if (KISS_CTX_WORD(c) <= KISS_EMPTY_CTX) { // refresh path
-                    const uint32_t cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm);
+                    const uint32_t cls = item_class<false>(pk, srcP, srcC, p0 + a, emitmask, &v, &c, rm, REMAP ? nullptr : srcK);
                     take(e, cls & 3u, cls < 4u ? 1u : 0u);
                 } else {
                     const uint32_t pc = c & 3u;
@@ -339,7 +399,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
         for (int e = 0; e < IN_ITEMS; e++) {
             const uint64_t i = i0 + (uint64_t)e;
             uint32_t cls = 4u, v = 0, c = 0;
-            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)DIR * (int64_t)i, emitmask, &v, &c, rm);
+            if (i < N) cls = item_class<REMAP>(pk, srcP, srcC, beg + (int64_t)DIR * (int64_t)i, emitmask, &v, &c, rm, REMAP ? nullptr : srcK);
             take(e, cls & 3u, cls < 4u ? 1u : 0u);
             vv[e] = v;
             cc[e] = c;
@@ -411,6 +471,13 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
             const int64_t lo = DIR > 0 ? d0 : d0 - 3;
             *reinterpret_cast<U4 *>(SA + lo) = wp;
             *reinterpret_cast<U4 *>(CTX + lo) = wc;
+            if (CLS) { // the four words' class bytes: one 4-byte store (byte-aligned)
+                struct __attribute__((packed, aligned(1))) B4 {
+                    uint32_t v;
+                };
+                reinterpret_cast<B4 *>(CLS + lo)->v =
+                    cls_byte(wc.v[0]) | (cls_byte(wc.v[1]) << 8) | (cls_byte(wc.v[2]) << 16) | (cls_byte(wc.v[3]) << 24);
+            }
         } else {
             for (uint32_t li = l0; li < l0 + 4u && li < total; li++) {
                 const uint32_t c2_ = (li >= c1 ? 1u : 0u) + (li >= c2 ? 1u : 0u) + (li >= c3 ? 1u : 0u);
@@ -418,6 +485,7 @@ __global__ __launch_bounds__(IN_THREADS) void k_induce_scatter(const uint64_t *_
                 const int64_t d = dbk + (int64_t)DIR * (int64_t)li;
                 SA[d] = stP[li];
                 CTX[d] = stC[li];
+                if (CLS) CLS[d] = (uint8_t)cls_byte(stC[li]);
             }
         }
     }
@@ -657,7 +725,7 @@ template <bool REMAP> // REMAP: one round over the LMS list (selfclass < 0)
 __global__ __launch_bounds__(SM_THREADS) void k_induce_small(const uint64_t *__restrict__ pk, const uint32_t *srcP0,
                                                             uint32_t *srcC0, int64_t beg0, uint64_t N0, int dir,
                                                             uint32_t emitmask, int selfclass, DstPos dst, uint32_t *SA,
-                                                            uint32_t *CTX, uint32_t *out, LmsRemap rm)
+                                                            uint32_t *CTX, uint32_t *out, LmsRemap rm, uint8_t *CLS)
 {
     __shared__ int64_t heads[4];
     __shared__ uint32_t wtot[SM_THREADS / 64][4];
@@ -701,6 +769,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_induce_small(const uint64_t *__r
                 int64_t d = heads[cls] + (int64_t)dir * (int64_t)o;
                 SA[d] = v - 1u;
                 CTX[d] = child_ctx(cw);
+                if (CLS) CLS[d] = (uint8_t)cls_byte(child_ctx(cw));
             }
             if (threadIdx.x < 4) {
                 uint32_t t = 0;
@@ -750,6 +819,10 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
     DstPos dp;
     for (int c = 0; c < 4; c++) dp.p[c] = sw.pos[c];
     ctx->stats.induce_passes++;
+    // class bytes of the source words: only the arrays parallel to SA have them (every kernel that writes a context word
+    // there writes its byte: k_induce_scatter, k_induce_small, k_chain_write, k_chain_term_write); the hooks build can
+    // switch their use off, and does so with the one-pass form, whose kernel does not write them
+    uint8_t *const srcK = (srcC == ctx->CTX && ctx->CLS && !ctx->opts.no_class_bytes && !ctx->opts.induce_one_pass) ? ctx->CLS : nullptr;
     const uint64_t small_max = ctx->opts.induce_small_max >= 64 && ctx->opts.induce_small_max <= (1u << 20) ? ctx->opts.induce_small_max
                                                                                                            : (uint64_t)SMALL_MAX;
     if (N <= small_max) {
@@ -757,10 +830,10 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, N);
             if (remap)
                 hipLaunchKernelGGL(k_induce_small<true>, dim3(1), dim3(SM_THREADS), 0, ctx->stream, ctx->pk, srcP, srcC, beg, N,
-                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->CLS);
             else
                 hipLaunchKernelGGL(k_induce_small<false>, dim3(1), dim3(SM_THREADS), 0, ctx->stream, ctx->pk, srcP, srcC, beg, N,
-                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                                   sw.dir, emitmask, selfclass, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->CLS);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_readback(ctx, ctx->d_small, 5));
@@ -791,10 +864,10 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
             KTimer t(ctx, KISS_HIP_K_INDUCE_COUNT, N);
             if (remap)
                 hipLaunchKernelGGL(k_induce_count<true>, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream,
-                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm);
+                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm, srcK);
             else
                 hipLaunchKernelGGL(k_induce_count<false>, dim3((unsigned)div_up(tiles, IN_WAVES)), dim3(IN_THREADS), 0, ctx->stream,
-                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm);
+                                   ctx->pk, srcP, srcC, beg, N, sw.dir, emitmask, ctx->ind_counts, tiles, rm, srcK);
             KCHECK(hipGetLastError());
         }
         KTRY(kiss_scan_u32(ctx, ctx->ind_counts, ctx->ind_counts, 4 * tiles + 1));
@@ -802,13 +875,13 @@ int run_pass(Sweep &sw, const uint32_t *srcP, uint32_t *srcC, int64_t beg, uint6
             KTimer t(ctx, KISS_HIP_K_INDUCE_SCATTER, N);
             if (remap)
                 hipLaunchKernelGGL((k_induce_scatter<true, 1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->CLS, srcK);
             else if (sw.dir > 0)
                 hipLaunchKernelGGL((k_induce_scatter<false, 1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->CLS, srcK);
             else
                 hipLaunchKernelGGL((k_induce_scatter<false, -1>), dim3((unsigned)tiles), dim3(IN_THREADS), 0, ctx->stream, ctx->pk, srcP,
-                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm);
+                                   srcC, beg, N, emitmask, ctx->ind_counts, tiles, dp, sw.SA, ctx->CTX, ctx->d_small, rm, ctx->CLS, srcK);
             KCHECK(hipGetLastError());
         }
         }
@@ -961,7 +1034,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_expand(const uint32_t *src
 __global__ __launch_bounds__(CH_THREADS) void k_chain_write(const uint64_t *__restrict__ pk,
                                                            const uint64_t *__restrict__ sorted_key,
                                                            const uint32_t *__restrict__ sorted_pos, uint64_t E,
-                                                           int64_t dst, int dir, uint32_t *SA, uint32_t *CTX)
+                                                           int64_t dst, int dir, uint32_t *SA, uint32_t *CTX, uint8_t *CLS)
 {
     uint64_t e = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     if (e >= E) return;
@@ -970,6 +1043,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_write(const uint64_t *__re
     const int64_t d = dst + (int64_t)dir * (int64_t)e;
     SA[d] = u;
     CTX[d] = cw;
+    if (CLS) CLS[d] = (uint8_t)cls_byte(cw);
 }
 
 struct TermDst {
@@ -980,7 +1054,7 @@ struct TermDst {
 __global__ __launch_bounds__(CH_THREADS) void k_chain_term_write(const uint64_t *__restrict__ pk,
                                                                 const uint64_t *__restrict__ sorted_tkey,
                                                                 const uint32_t *__restrict__ sorted_tpos, uint64_t T,
-                                                                TermDst td, int dir, uint32_t *SA, uint32_t *CTX)
+                                                                TermDst td, int dir, uint32_t *SA, uint32_t *CTX, uint8_t *CLS)
 {
     uint64_t j = (uint64_t)blockIdx.x * CH_THREADS + threadIdx.x;
     if (j >= T) return;
@@ -989,7 +1063,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_chain_term_write(const uint64_t 
     const uint32_t u = sorted_tpos[j];
     const int64_t d = td.p[x] + (int64_t)dir * (int64_t)(j - td.off[x]);
     SA[d] = u;
-    CTX[d] = kiss_load_ctx(pk, u) | ((uint32_t)(sorted_tkey[j] & 1ull) << 31);
+    const uint32_t cw = kiss_load_ctx(pk, u) | ((uint32_t)(sorted_tkey[j] & 1ull) << 31);
+    CTX[d] = cw;
+    if (CLS) CLS[d] = (uint8_t)cls_byte(cw);
 }
 
 int verify_part(kiss_hip_ctx *ctx, const uint32_t *SA, int64_t lo, int64_t hi, uint32_t c, uint64_t n, const char *what);
@@ -1049,7 +1125,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             KTRY(kiss_radix_sort(ctx, rb, E, tshift, 0, &res)); // step index t sits in bits tshift..63
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, E);
             hipLaunchKernelGGL(k_chain_write, dim3((unsigned)div_up(E, CH_THREADS)), dim3(CH_THREADS), 0, ctx->stream,
-                               ctx->pk, rb.key[res], rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX);
+                               ctx->pk, rb.key[res], rb.pos[res], E, dst, sw.dir, sw.SA, ctx->CTX, ctx->CLS);
             KCHECK(hipGetLastError());
             if (ctx->opts.verify) {
                 int64_t lo = sw.dir > 0 ? dst : dst - (int64_t)E + 1, hi = sw.dir > 0 ? dst + (int64_t)E : dst + 1;
@@ -1077,7 +1153,7 @@ int run_collapse(Sweep &sw, uint32_t c, int64_t beg, uint64_t N, uint32_t termma
             td.off[4] = o;
             KTimer t(ctx, KISS_HIP_K_INDUCE_SMALL, T);
             hipLaunchKernelGGL(k_chain_term_write, dim3((unsigned)div_up(T, CH_THREADS)), dim3(CH_THREADS), 0,
-                               ctx->stream, ctx->pk, tb.key[res], tb.pos[res], T, td, sw.dir, sw.SA, ctx->CTX);
+                               ctx->stream, ctx->pk, tb.key[res], tb.pos[res], T, td, sw.dir, sw.SA, ctx->CTX, ctx->CLS);
             KCHECK(hipGetLastError());
         }
         for (int x = 0; x < 4; x++) sw.pos[x] += (int64_t)sw.dir * (int64_t)cnt[x];

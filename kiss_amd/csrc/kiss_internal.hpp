@@ -27,6 +27,7 @@ struct KissOpts {
     bool pivot_from_round2 = false;// KISS_HIP_PIVOT_FROM_ROUND2
     bool pair_keys = false;        // KISS_HIP_PAIR_KEYS: gather the round's key for pairs as well
     bool no_fc0_onepass = false;   // KISS_HIP_NO_FC0_ONEPASS: count + scan + compact after round 0
+    bool no_class_bytes = false;   // KISS_HIP_NO_CLASS_BYTES: the induction's count pass reads the context words (rounds 1-3)
     bool no_pivot_ctx = false;     // KISS_HIP_NO_PIVOT_CTX
     bool no_taint = false;         // KISS_HIP_NO_TAINT: the suffix-array form compares every neighbour pair
     bool isa_direct = false;       // KISS_HIP_ISA_DIRECT: inverse SA by plain random scatter
@@ -135,6 +136,7 @@ struct kiss_hip_ctx {
     // classification scratch
     uint32_t *tile_gp = nullptr;   // per 256-word tile: bit0 = G, bit1 = P  -> later: carry-in of the tile
     uint32_t *tile_cnt = nullptr;  // per tile LMS count -> exclusive offsets
+    uint8_t *CLS = nullptr;        // one class byte per word of CTX (induce.hip: cls_byte), allocated with it
     uint32_t *cl_part = nullptr;   // classification: one row of partial sums per workgroup (classify.hip: k_sum_rows)
     uint64_t n_tiles_cap = 0;
     uint32_t *d_counts = nullptr;  // 16 x u32: cnt[4], cntS[4], cntLMS[4], far_lms, spare
