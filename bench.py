@@ -575,7 +575,7 @@ def rehearse_sharded(torch, dist, kiss_amd, S, n, k, rank, local_rank, device):
 
 # 1-GPU phase times of the headline configuration (ms; DESIGN.md 4, round 4 records) and the xGMI rate DESIGN.md 7 prices
 # the two data-path transfers at: the inputs of the expected strong-scaling curve
-MODEL_1GPU_MS = {"pack": 0.65, "classify": 4.1, "sort": 52.7, "induce": 19.4, "histogram": 3.4, "partition": 5.6}
+MODEL_1GPU_MS = {"pack": 0.65, "classify": 4.0, "sort": 52.5, "induce": 17.9, "histogram": 3.4, "partition": 5.6}
 MODEL_LINK_GBPS = 153.0
 MODEL_LMS_FRACTION = 0.2906  # LMS suffixes per base of the synthetic chm13-size text (905 939 973 / 3 117 292 070)
 
