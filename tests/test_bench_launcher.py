@@ -151,7 +151,7 @@ def test_scaling_model_of_the_sharded_line():
     assert m[1]["exchange_bytes_per_rank"] == 0 and m[1]["gather_bytes_into_rank0"] == 0
     assert abs(m[2]["exchange_bytes_per_rank"] - 12 * b.MODEL_LMS_FRACTION * b.CHM13_N / 4) < 1e6   # half of a rank's half
     assert abs(m[8]["gather_bytes_into_rank0"] - 8 * b.MODEL_LMS_FRACTION * b.CHM13_N * 7 / 8) < 1e6
-    assert 3.0 < m[8]["ceiling_speedup"] < 4.0 and "model only" in m[8]["status"]
+    assert 3.0 < m[8]["ceiling_speedup"] < 4.5 and "model only" in m[8]["status"]
     # a text of another length scales the phases with n
     assert abs(b.scaling_model(4, b.CHM13_N // 2)["expected_ms"] - m[4]["expected_ms"] / 2) < 0.3
 
