@@ -153,7 +153,9 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_adjacent(const uint64_t *__r
 }
 
 // small segments: final rank of every member, written straight to its final slot;
-// big segments: flagged for the radix path.  big[i] = (1 << 32) | (first item of a big segment)
+// big segments: flagged for the radix path.  big[i] = 0: finished here, 1: member of a big segment, 3: its first member
+// (one byte per item since round 4: k_bigb_count / k_bigb_compact below count and compact them tile by tile; the
+//  8-byte flag words of rounds 1-3 went through a full scan, 5 GB of traffic for 35 M big-segment items)
 __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__restrict__ pk, uint64_t n,
                                                           const uint64_t *__restrict__ key,
                                                           const uint32_t *__restrict__ pos,
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
                                                           const uint32_t *__restrict__ segstart, uint64_t count,
                                                           uint64_t off, uint64_t depth, uint32_t small_seg,
                                                           const uint8_t *__restrict__ inorder,
-                                                          uint32_t *__restrict__ out, uint64_t *__restrict__ big,
+                                                          uint32_t *__restrict__ out, uint8_t *__restrict__ big,
                                                           uint32_t *__restrict__ nbig,
                                                           const uint32_t *__restrict__ tctx, // first round only: the
                                                           uint32_t *__restrict__ octx,       // items' context words
@@ -238,33 +240,10 @@ __global__ __launch_bounds__(LS_THREADS) void k_seg_finish(const uint64_t *__res
         else if (taint) octx[dst] = KISS_CTX_TAINT; // no word yet (gathered at placement), but tainted
         big[i] = 0;
     } else if (valid) {
-        big[i] = (1ull << 32) | (uint64_t)((uint32_t)i == a ? 1u : 0u);
+        big[i] = (uint32_t)i == a ? (uint8_t)3 : (uint8_t)1;
     }
     (void)nbig; // the number of big-segment items comes out of the flag scan (one address hit by every wave's
                 // atomicAdd cost more than the rest of this kernel)
-}
-
-__global__ __launch_bounds__(LS_THREADS) void k_big_compact(const uint64_t *__restrict__ key,
-                                                           const uint32_t *__restrict__ pos,
-                                                           const uint32_t *__restrict__ slot, uint64_t count,
-                                                           const uint64_t *__restrict__ big,
-                                                           const uint64_t *__restrict__ ex,
-                                                           uint64_t *__restrict__ bkey, uint32_t *__restrict__ bpos,
-                                                           uint32_t *__restrict__ bseg, uint32_t *__restrict__ bslot,
-                                                           uint32_t *__restrict__ bsegstart)
-{
-    uint64_t i = (uint64_t)blockIdx.x * LS_THREADS + threadIdx.x;
-    if (i >= count) return;
-    uint64_t f = big[i];
-    if (!(f >> 32)) return;
-    uint64_t e = ex[i];
-    uint32_t kx = (uint32_t)(e >> 32);
-    const uint32_t sid = (uint32_t)(e & 0xFFFFFFFFull) + (uint32_t)(f & 1ull) - 1u;
-    if (key) bkey[kx] = key[i]; // (null: a pivot round follows, which keys the members against its reference string)
-    bpos[kx] = pos[i];
-    bslot[kx] = slot[i]; // slots stay in index order: the k-th item after the sort takes the k-th slot
-    bseg[kx] = sid;
-    if (f & 1ull) bsegstart[sid] = kx;
 }
 
 // ---- big segments: three-way split around a pivot key before any radix pass ---------------------------------
@@ -1192,6 +1171,102 @@ __global__ void k_fc_total(const uint64_t *__restrict__ tcnt, const uint64_t *__
     if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = tex[tiles - 1] + tcnt[tiles - 1];
 }
 
+// ---- the items of big segments after a refinement round (k_seg_finish's byte flags): count per tile, scan over tiles,
+// compact -- the tile-wise form of the flag + compaction above ---------------------------------------------------------
+__device__ __forceinline__ void bigb_flags(const uint8_t *__restrict__ bb, uint64_t i0, uint64_t count, uint32_t &valid,
+                                           uint32_t &bigmask, uint32_t &headmask)
+{
+    valid = i0 >= count ? 0u : (count - i0 >= FC_ITEMS ? (uint32_t)FC_ITEMS : (uint32_t)(count - i0));
+    bigmask = headmask = 0;
+    if (!valid) return;
+    uint64_t w = 0;
+    if (valid == FC_ITEMS) w = *reinterpret_cast<const uint64_t *>(bb + i0);
+    else
+        for (uint32_t e = 0; e < valid; e++) w |= (uint64_t)bb[i0 + e] << (8 * e);
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        const uint32_t f = (uint32_t)(w >> (8 * e)) & 3u;
+        bigmask |= (f & 1u) << e;
+        headmask |= (f >> 1) << e;
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_bigb_count(const uint8_t *__restrict__ bb, uint64_t count,
+                                                          uint64_t *__restrict__ tcnt)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint32_t valid, sm, hm;
+    bigb_flags(bb, i0, count, valid, sm, hm);
+    uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ns += __shfl_xor(ns, d, 64);
+        nh += __shfl_xor(nh, d, 64);
+    }
+    if (lane_id() == 0) {
+        ws[threadIdx.x >> 6][0] = ns;
+        ws[threadIdx.x >> 6][1] = nh;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t a = 0, b = 0;
+        for (int w = 0; w < FC_THREADS / 64; w++) {
+            a += ws[w][0];
+            b += ws[w][1];
+        }
+        tcnt[blockIdx.x] = (a << 32) | b;
+    }
+}
+
+__global__ __launch_bounds__(FC_THREADS) void k_bigb_compact(const uint8_t *__restrict__ bb, const uint64_t *__restrict__ key,
+                                                            const uint32_t *__restrict__ pos,
+                                                            const uint32_t *__restrict__ slot, uint64_t count,
+                                                            const uint64_t *__restrict__ tex, uint64_t *__restrict__ bkey,
+                                                            uint32_t *__restrict__ bpos, uint32_t *__restrict__ bseg,
+                                                            uint32_t *__restrict__ bslot, uint32_t *__restrict__ bsegstart)
+{
+    __shared__ uint32_t ws[FC_THREADS / 64][2];
+    const int wave = threadIdx.x >> 6;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * FC_THREADS + threadIdx.x) * FC_ITEMS;
+    uint32_t valid, sm, hm;
+    bigb_flags(bb, i0, count, valid, sm, hm);
+    const uint32_t ns = (uint32_t)__popc(sm), nh = (uint32_t)__popc(hm);
+    uint32_t is = ns, ih = nh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t os = __shfl_up(is, d, 64), oh = __shfl_up(ih, d, 64);
+        if ((int)lane_id() >= d) {
+            is += os;
+            ih += oh;
+        }
+    }
+    if (lane_id() == 63) {
+        ws[wave][0] = is;
+        ws[wave][1] = ih;
+    }
+    __syncthreads();
+    const uint64_t te = tex[blockIdx.x];
+    uint32_t bs = (uint32_t)(te >> 32) + (is - ns), bh = (uint32_t)(te & 0xFFFFFFFFull) + (ih - nh);
+    for (int w = 0; w < wave; w++) {
+        bs += ws[w][0];
+        bh += ws[w][1];
+    }
+#pragma unroll
+    for (int e = 0; e < FC_ITEMS; e++) {
+        if ((sm >> e) & 1u) {
+            const uint32_t kx = bs++;
+            if ((hm >> e) & 1u) bh++;
+            const uint32_t sid = bh - 1u; // big-segment heads up to and including this item's own
+            if (key) bkey[kx] = key[i0 + e]; // (null: a pivot round follows, which keys the members against its reference string)
+            bpos[kx] = pos[i0 + e];
+            bslot[kx] = slot[i0 + e]; // slots stay in index order: the k-th item after the sort takes the k-th slot
+            bseg[kx] = sid;
+            if ((hm >> e) & 1u) bsegstart[sid] = kx;
+        }
+    }
+}
+
 // flag + compact of `count` sorted items, in two halves so a caller can size buffers in between:
 // fc_count + fc_read_total: (survivors << 32) | surviving segments;  fc_compact: the data movement
 template <int SRC>
@@ -1434,6 +1509,7 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
                                K1, no_pair_keys ? Gc : (const uint32_t *)nullptr, SSc, 3u, pivot_ahead ? small_seg : 0xFFFFFFFFu);
             KCHECK(hipGetLastError());
         }
+        uint8_t *bigb = nullptr;
         hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;
         if (dbg) {
             (void)hipEventCreate(&dbg_e0);
@@ -1443,19 +1519,28 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         {
             KTimer t(ctx, KISS_HIP_K_SEGRANK, count);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, SSc + nseg, (uint32_t)count, d_nbig);
-            uint8_t *inorder = reinterpret_cast<uint8_t *>(F2); // F2 is free until the big-segment scan below
+            uint8_t *inorder = reinterpret_cast<uint8_t *>(F2); // F2 is free until the pivot / big-segment steps below
+            bigb = inorder + ((count + 15) & ~15ull);           // the big-segment flags of k_seg_finish, behind them
             hipLaunchKernelGGL(k_seg_adjacent, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Gc, SSc, count, off,
                                depth, small_seg, inorder);
             hipLaunchKernelGGL(k_seg_finish, dim3(grid), dim3(T), 0, ctx->stream, ctx->pk, n, K1, Pc, Sc, Gc, SSc,
-                               count, off, depth, small_seg, inorder, ctx->lms_sorted_far, F1, d_nbig,
+                               count, off, depth, small_seg, inorder, ctx->lms_sorted_far, bigb, d_nbig,
                                (have_tctx && first_refine) ? ctx->bslot : (const uint32_t *)nullptr, ctx->lms_ctx_far, ctx->hfar);
             KCHECK(hipGetLastError());
         }
         ctx->stats.lms_rounds++;
         ctx->stats.sort_item_rounds += count;
-        // big-segment items and segments: totals of the flag scan
-        KTRY(kiss_scan_u64(ctx, F1, F2, count));
-        hipLaunchKernelGGL(k_last_total, dim3(1), dim3(64), 0, ctx->stream, F1, F2, count, d_total);
+        // big-segment items and segments: counted tile by tile from the byte flags, scanned over the tiles
+        const uint64_t btiles = div_up(count, FC_TILE);
+        uint64_t *const btcnt = F1, *const btex = F1 + btiles;
+        if (2 * btiles > ctx->t_cap) return KINTERNAL();
+        {
+            KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
+            hipLaunchKernelGGL(k_bigb_count, dim3((unsigned)btiles), dim3(FC_THREADS), 0, ctx->stream, bigb, count, btcnt);
+            KCHECK(hipGetLastError());
+        }
+        KTRY(kiss_scan_u64(ctx, btcnt, btex, btiles));
+        hipLaunchKernelGGL(k_fc_total, dim3(1), dim3(64), 0, ctx->stream, btcnt, btex, btiles, d_total);
         uint64_t bt;
         KTRY(read_u64(ctx, d_total, &bt));
         const uint64_t nbig = bt >> 32;
@@ -1479,8 +1564,9 @@ int kiss_lms_sort(kiss_hip_ctx *ctx, uint64_t n, uint32_t k, uint64_t depth)
         const unsigned bgrid = (unsigned)div_up(nbig, T);
         {
             KTimer t(ctx, KISS_HIP_K_FLAG_COMPACT, count);
-            hipLaunchKernelGGL(k_big_compact, dim3(grid), dim3(T), 0, ctx->stream, pivot_ahead ? (const uint64_t *)nullptr : K1, Pc,
-                               Sc, count, F1, F2, ctx->bkeyA, ctx->bposA, ctx->bsegA, ctx->bslot, bss);
+            hipLaunchKernelGGL(k_bigb_compact, dim3((unsigned)btiles), dim3(FC_THREADS), 0, ctx->stream, bigb,
+                               pivot_ahead ? (const uint64_t *)nullptr : K1, Pc, Sc, count, btex, ctx->bkeyA, ctx->bposA, ctx->bsegA,
+                               ctx->bslot, bss);
             hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(64), 0, ctx->stream, bss + nbigseg, (uint32_t)nbig, (uint32_t *)nullptr);
             KCHECK(hipGetLastError());
         }
