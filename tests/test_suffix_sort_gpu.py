@@ -322,6 +322,25 @@ def test_one_pass_induction_equals_count_scan_scatter(hctx, oracle, monkeypatch)
     monkeypatch.delenv("KISS_HIP_INDUCE_ONE_PASS", raising=False)
 
 
+def test_count_pass_on_class_bytes_equals_the_word_path(hctx, oracle, monkeypatch):
+    # round 4: every kernel that writes a context word beside SA also writes one class byte, and the count pass of
+    # the induction reads the bytes (2 KiB per tile, aligned 16-byte pieces; a byte that says "no bases left" sends its tile
+    # to the word path, which refreshes word and byte).  KISS_HIP_NO_CLASS_BYTES (hooks build) is the form of rounds 1-3.
+    # Texts: passes of thousands of tiles; runs of one base of 17 and of 40 (context words run empty: the refresh path, in
+    # both sweeps); a text of one base; lengths that leave the byte stretches of the tiles at every alignment.
+    import kiss_amd
+    texts = [gen.genome_like(5_000_000, 43), np.repeat(gen.iid(300_000, 7), 17), np.repeat(gen.iid(90_000, 8), 40),
+             np.zeros(300_001, np.uint8)] + [gen.genome_like(700_000 + d, 44 + d) for d in (1, 5, 11)]
+    for S in texts:
+        for k, algo in ((256, 0), (kiss_amd.K_UNBOUNDED, 1)):
+            want = oracle.suffix_sort(S, k)
+            monkeypatch.delenv("KISS_HIP_NO_CLASS_BYTES", raising=False)
+            assert np.array_equal(hctx.suffix_sort(S, k, algo=algo), want), (S.size, k, "class bytes")
+            monkeypatch.setenv("KISS_HIP_NO_CLASS_BYTES", "1")
+            assert np.array_equal(hctx.suffix_sort(S, k, algo=algo), want), (S.size, k, "context words")
+    monkeypatch.delenv("KISS_HIP_NO_CLASS_BYTES", raising=False)
+
+
 def test_kernel_class_timing_can_be_limited_to_chosen_classes(oracle):
     # kiss_hip_ctx_set_profiling_mask: HIP events only around the launches of the named classes (what bench.py does for the
     # dominant kernel inside its timed region); the result does not depend on what is timed
