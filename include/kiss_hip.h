@@ -172,8 +172,8 @@ int kiss_hip_ctx_release_io_buffers(kiss_hip_ctx *ctx);
  *   k  : order; 0xFFFFFFFF (the CLI's -k -1) or any k >= n means the exact suffix array.
  *   SA : caller-allocated, n+1 entries; SA[0] = n (sentinel), SA[1..n] a permutation.
  * One-shot: uploads, sorts and downloads on a context the library keeps for `device` between one-shot calls (created by
- * the first call, grown when a longer text arrives; a chm13-size context is 77 GB of work arrays and the reference's
- * facade allocates its 5 bytes per base per call too, kiss1_core.hpp:243-257 -- at 30 bytes per base that is not free).
+ * the first call, grown when a longer text arrives; a chm13-size context is 80 GB of work arrays and the reference's
+ * facade allocates its 5 bytes per base per call too, kiss1_core.hpp:243-257 -- at 26 bytes per base that is not free).
  * One one-shot call at a time per device; kiss_hip_release_cached_contexts() gives the memory back.
  * n == 0 yields SA = {0} (kiss1_core.hpp:237-238).
  */
