@@ -974,6 +974,9 @@ def main():
             out["config"]["parallelism"] = ("ONE process driving devices %s through kiss_hip_multi_* (LMS sort sharded by key "
                                             "range, peer copies, induction on the first device)" % args.multi_abi)
             out["config"]["multi_phase_ms"] = {kk: v / args.steps for kk, v in multi_phase.items()}
+            # the model's expectation for as many DISTINCT devices as shares were asked for (shares of one GPU, the only
+            # form a one-GPU box can run, compete for it: they price the mechanics, not the curve)
+            out["config"]["scaling_model"] = scaling_model(len(args.multi_abi.split(",")), n)
         if not args.no_verify:
             out.update(verify_leg(ctx, S, SA, n, k, args.seed, args.iid or data == "file", algo,
                                   with_fnv=(world == 1 and not args.no_fnv), harsh=args.harsh))
