@@ -797,7 +797,12 @@ def main():
     else:
         world, rank, local_rank = 1, 0, 0
     visible = torch.cuda.device_count()  # does not initialise the GPU
-    if visible < world or local_rank >= visible:
+    # KISS_BENCH_SHARE_GPU=1 (tests): every rank uses GPU 0 and the ranks talk gloo (RCCL refuses two ranks on one device)
+    # -- the whole N > 1 code path of this file on a one-GPU box, minus the transport
+    share = world > 1 and os.environ.get("KISS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
+    if not share and (visible < world or local_rank >= visible):
         print("[bench] rank %d: %d GPUs asked for, %d visible: not reporting a number for a smaller job"
               % (rank, world, visible), file=sys.stderr, flush=True)
         sys.exit(EXIT_TOO_FEW_DEVICES)
@@ -808,7 +813,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -930,7 +938,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -965,6 +973,9 @@ def main():
         out = assemble_line(args, world, sharded, n, k, algo, elapsed, agg, prof_agg, prof_steps, stage, last_stats,
                             ctx.workspace_bytes(), phase_ms=phase_ms, sharded_error=sharded_error, data=data,
                             text_desc=text_desc)
+        if share:
+            out["config"]["ranks_share_one_gpu"] = ("KISS_BENCH_SHARE_GPU=1: every rank on GPU 0, gloo transport -- a test of this "
+                                                    "file's N > 1 code path, not a measurement")
         if phase_extra:
             out["config"]["sharded_phase_ms_rank0"] = dict(phase_extra)
             out["config"]["sharded_phase_ms_from"] = "one extra step after the timed region, phases closed by device synchronisations"

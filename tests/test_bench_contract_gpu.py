@@ -139,3 +139,27 @@ def test_sharded_rehearsal_passes_on_one_rank_and_reports_a_failure(monkeypatch)
         assert err is not None and "boom" in err and "rank 0" in err
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_the_two_rank_code_path_of_bench_with_both_ranks_on_the_one_gpu():
+    """`python bench.py --gpus 2` end to end on a one-GPU box: KISS_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and makes them
+    talk gloo (RCCL refuses two ranks on one device).  Everything else is the code the driver's N = 2 run executes: the
+    self-launching parent, the same text on both ranks, the smaller reservation of rank 1, the rehearsal and its agreement,
+    the timed loop between barriers, the extra step with phase times, rank 0's verification, the assembled line."""
+    env = dict(os.environ, KISS_BENCH_SHARE_GPU="1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--text-len", "30000000", "--steps", "2",
+                        "--warmup", "1", "--cpu-sample", "0", "--no-fnv", "--rank-timeout", "600"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] and j["verified"] is True
+    cfg = j["config"]
+    assert "sharded_error" not in cfg and "ranks_share_one_gpu" in cfg
+    assert set(cfg["sharded_phase_ms_rank0"]) >= {"sort", "induce"} or len(cfg["sharded_phase_ms_rank0"]) >= 4
+    assert cfg["scaling_model"]["gpus"] == 2
+    assert j["value"] == pytest.approx(30000000 * 2 / (2 * j["ms_per_step"] / 1e3), rel=1e-6)
