@@ -142,7 +142,8 @@ def test_sharded_rehearsal_passes_on_one_rank_and_reports_a_failure(monkeypatch)
 
 
 @pytest.mark.gpu
-def test_the_two_rank_code_path_of_bench_with_both_ranks_on_the_one_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_the_two_rank_code_path_of_bench_with_both_ranks_on_the_one_gpu(launcher):
     """`python bench.py --gpus 2` end to end on a one-GPU box: KISS_BENCH_SHARE_GPU=1 puts both ranks on GPU 0 and makes them
     talk gloo (RCCL refuses two ranks on one device).  Everything else is the code the driver's N = 2 run executes: the
     self-launching parent, the same text on both ranks, the smaller reservation of rank 1, the rehearsal and its agreement,
@@ -150,11 +151,16 @@ def test_the_two_rank_code_path_of_bench_with_both_ranks_on_the_one_gpu():
     env = dict(os.environ, KISS_BENCH_SHARE_GPU="1", MASTER_PORT=str(29700 + os.getpid() % 200))
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--text-len", "30000000", "--steps", "2",
-                        "--warmup", "1", "--cpu-sample", "0", "--no-fnv", "--rank-timeout", "600"],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    bench_args = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--text-len", "30000000", "--steps", "2", "--warmup", "1",
+                  "--cpu-sample", "0", "--no-fnv", "--rank-timeout", "600"]
+    if launcher == "self":  # bench.py starts its two ranks itself
+        cmd = [sys.executable] + bench_args
+    else:  # the driver's form: one rank per process under torch.distributed.run
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", env["MASTER_PORT"]] + bench_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] and j["verified"] is True
